@@ -1,0 +1,228 @@
+"""Python mirror of the reference's interface for the Viterbi path, over the C ABI.
+
+Same names and argument meaning as the reference: Machine.fromFile (trans.cpp:477-482),
+MutatorParams from CLI flags (t/dnastore.cpp:119-129) or --error-file JSON
+(mutator.cpp:18-49), decodeFastSeqs(filename, machine, params) (viterbi.cpp:306-320),
+ViterbiMatrix.traceback()/loglike() (viterbi.h:94-102) batched as ViterbiDecoder.decode.
+All computation happens in libdnastore_amd.so; nothing here touches the DP.
+"""
+import ctypes
+
+import numpy as np
+
+from . import lib as _l
+
+
+class Machine:
+    def __init__(self, handle):
+        self._h = handle
+
+    @staticmethod
+    def fromFile(path):
+        h = ctypes.c_void_p()
+        _l.check(_l.lib().dnas_machine_load_json(str(path).encode(), ctypes.byref(h)))
+        return Machine(h)
+
+    @staticmethod
+    def fromJSON(text):
+        b = text.encode() if isinstance(text, str) else text
+        h = ctypes.c_void_p()
+        _l.check(_l.lib().dnas_machine_parse_json(b, len(b), ctypes.byref(h)))
+        return Machine(h)
+
+    def nStates(self):
+        return _l.lib().dnas_machine_n_states(self._h)
+
+    def toJSON(self):
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        _l.check(_l.lib().dnas_machine_write_json(self._h, ctypes.byref(p), ctypes.byref(n)))
+        s = ctypes.string_at(p, n.value).decode()
+        _l.lib().dnas_free(p)
+        return s
+
+    def _encode(self, fn, data):
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        _l.check(fn(self._h, data, len(data), ctypes.byref(p), ctypes.byref(n)))
+        s = ctypes.string_at(p, n.value).decode()
+        _l.lib().dnas_free(p)
+        return s
+
+    def encodeSymbols(self, symbols):
+        """Encoder::encodeSymbolString + close (encoder.h:33-57,238-241) -> DNA string."""
+        return self._encode(_l.lib().dnas_encode_symbols, symbols.encode() if isinstance(symbols, str) else symbols)
+
+    def encodeBytes(self, payload):
+        """Encoder::encodeString/encodeStream (encoder.h:222-237): bits LSB first -> DNA string."""
+        return self._encode(_l.lib().dnas_encode_bytes, bytes(payload))
+
+    def __del__(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _l.lib().dnas_machine_free(self._h)
+            self._h = ctypes.c_void_p()
+
+
+class MutatorParams:
+    def __init__(self, c):
+        self.c = c
+
+    @staticmethod
+    def fromFlags(sub=.01, iv=10., dup=.001, del_open=.001, del_ext=.01, global_=False, length=12):
+        """--error-sub-prob/--error-iv-ratio/--error-dup-prob/--error-del-open/--error-del-ext/--error-global/--length."""
+        c = _l.MutatorParamsC()
+        _l.check(_l.lib().dnas_mutator_params_from_flags(sub, iv, dup, del_open, del_ext, int(bool(global_)), int(length),
+                                                         ctypes.byref(c)))
+        return MutatorParams(c)
+
+    @staticmethod
+    def fromFile(path):
+        c = _l.MutatorParamsC()
+        _l.check(_l.lib().dnas_mutator_params_load_json(str(path).encode(), ctypes.byref(c)))
+        return MutatorParams(c)
+
+    @property
+    def local(self):
+        return bool(self.c.local)
+
+    @property
+    def pLen(self):
+        return [self.c.p_len[i] for i in range(self.c.n_len)]
+
+
+_BASE = np.full(256, 255, dtype=np.uint8)
+for _i, _ch in enumerate("ACGT"):
+    _BASE[ord(_ch)] = _i
+    _BASE[ord(_ch.lower())] = _i
+
+
+def tokenize(seq):
+    """FastSeq::tokens over ACGT, case-insensitive (fastseq.cpp:9-39); raises on any other character."""
+    b = np.frombuffer(seq.encode() if isinstance(seq, str) else bytes(seq), dtype=np.uint8)
+    t = _BASE[b]
+    if (t == 255).any():
+        bad = chr(int(b[np.argmax(t == 255)]))
+        raise ValueError("Unknown symbol %s in sequence (alphabet is ACGT)" % bad)
+    return t
+
+
+class FlatModel:
+    """MachineScores + InputModel + MutatorScores as flat arrays (dnas_flatten)."""
+
+    def __init__(self, machine, params):
+        self._h = ctypes.c_void_p()
+        _l.check(_l.lib().dnas_flatten(machine._h, ctypes.byref(params.c), ctypes.byref(self._h)))
+        self.view = _l.lib().dnas_flat_view(self._h)
+
+    def arrays(self):
+        v = self.view.contents
+        n, ne, nn, d = v.n_states, v.n_emit, v.n_null, max(1, v.max_dup_len)
+
+        def arr(p, k, dt):
+            return np.ctypeslib.as_array(p, shape=(max(k, 1),))[:k].astype(dt).copy()
+        return dict(
+            n_states=n, max_dup_len=v.max_dup_len, n_len=v.n_len, local=v.local, n_emit=ne, n_null=nn,
+            ein_ptr=arr(v.ein_ptr, n + 1, np.int32), ein_src=arr(v.ein_src, ne, np.int32),
+            ein_score=arr(v.ein_score, ne, np.float64), ein_in=arr(v.ein_in, ne, np.uint8),
+            ein_base=arr(v.ein_base, ne, np.uint8),
+            nin_ptr=arr(v.nin_ptr, n + 1, np.int32), nin_src=arr(v.nin_src, nn, np.int32),
+            nin_score=arr(v.nin_score, nn, np.float64), nin_in=arr(v.nin_in, nn, np.uint8),
+            eout_ptr=arr(v.eout_ptr, n + 1, np.int32), eout_dst=arr(v.eout_dst, ne, np.int32),
+            nout_ptr=arr(v.nout_ptr, n + 1, np.int32), nout_dst=arr(v.nout_dst, nn, np.int32),
+            mdl=arr(v.mdl, n, np.uint8), ctx=arr(v.ctx, n * d, np.uint8).reshape(n, d), topo=arr(v.topo, n, np.int32),
+            scores=np.array([v.del_open, v.tan_dup, v.no_gap, v.del_extend, v.del_end] + list(v.sub)
+                            + [v.len[i] for i in range(v.n_len)]),
+            alphabet=v.alphabet.decode(), sym_logp=np.array(list(v.sym_logp)))
+
+    def __del__(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _l.lib().dnas_flat_free(self._h)
+            self._h = ctypes.c_void_p()
+
+
+def pack_reads(reads):
+    """list of str -> (read_offsets uint64[n+1], bases uint8[total]) as the C ABI wants them."""
+    toks = [tokenize(r) for r in reads]
+    off = np.zeros(len(toks) + 1, dtype=np.uint64)
+    if toks:
+        off[1:] = np.cumsum([len(t) for t in toks])
+    bases = np.concatenate(toks).astype(np.uint8) if toks and off[-1] else np.zeros(1, np.uint8)
+    return off, bases
+
+
+class ViterbiDecoder:
+    """A (machine, params) pair resident on one GPU; decode() is the batched ViterbiMatrix + traceback."""
+
+    def __init__(self, machine, params, device=0, arena_bytes=0):
+        self.flat = FlatModel(machine, params)
+        v = self.flat.view.contents
+        self.n_states, self.max_dup_len = v.n_states, v.max_dup_len
+        self._h = ctypes.c_void_p()
+        _l.check(_l.lib().dnas_model_create(self.flat.view, int(device), int(arena_bytes), ctypes.byref(self._h)))
+
+    def decode(self, reads, out_cap=None):
+        """reads: list of str (ACGT, any case) -> (decoded symbol strings, loglike float64[n], status uint8[n])."""
+        n = len(reads)
+        off, bases = pack_reads(reads)
+        lens = np.diff(off).astype(np.int64)
+        caps = (4 * lens + 64) if out_cap is None else np.full(n, int(out_cap), dtype=np.int64)
+        ooff = np.zeros(n + 1, dtype=np.uint64)
+        if n:
+            ooff[1:] = np.cumsum(caps)
+        sym = np.zeros(max(int(ooff[-1]), 1), dtype=np.uint8)
+        olen = np.zeros(max(n, 1), dtype=np.uint32)
+        ll = np.zeros(max(n, 1), dtype=np.float64)
+        st = np.zeros(max(n, 1), dtype=np.uint8)
+        _l.check(_l.lib().dnas_viterbi_batch(self._h, n, off.ctypes.data, bases.ctypes.data, sym.ctypes.data,
+                                             ooff.ctypes.data, olen.ctypes.data, ll.ctypes.data, st.ctypes.data))
+        out = [sym[int(ooff[i]):int(ooff[i]) + int(olen[i])].tobytes().decode() for i in range(n)]
+        return out, ll[:n], st[:n]
+
+    def decode_device(self, read_offsets, d_bases_ptr, d_sym_ptr, out_offsets, d_len_ptr, d_ll_ptr, d_status_ptr):
+        """dnas_viterbi_batch_device: raw device pointers (ints), host offset arrays; asynchronous."""
+        n = len(read_offsets) - 1
+        _l.check(_l.lib().dnas_viterbi_batch_device(self._h, n, read_offsets.ctypes.data, d_bases_ptr, d_sym_ptr,
+                                                    out_offsets.ctypes.data, d_len_ptr, d_ll_ptr, d_status_ptr))
+
+    def sync(self):
+        _l.check(_l.lib().dnas_model_sync(self._h))
+
+    def stats(self):
+        s = _l.BatchStatsC()
+        _l.check(_l.lib().dnas_model_last_stats(self._h, ctypes.byref(s)))
+        return {k: getattr(s, k) for k, _ in s._fields_}
+
+    def lattice(self, read_index, length):
+        """Lattice of one read of the last decode() call: float64 [L+1][D+2][N] (lanes S, D, T1..TD)."""
+        out = np.empty((length + 1, self.max_dup_len + 2, self.n_states), dtype=np.float64)
+        _l.check(_l.lib().dnas_model_read_lattice(self._h, int(read_index), int(length), out.ctypes.data))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _l.lib().dnas_model_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        self.close()
+
+
+def read_fastseqs(path):
+    """readFastSeqs (fastseq.cpp:123-148) -> [(name, seq)]."""
+    h = ctypes.c_void_p()
+    _l.check(_l.lib().dnas_fastseqs_read(str(path).encode(), ctypes.byref(h)))
+    L = _l.lib()
+    out = [(L.dnas_fastseqs_name(h, i).decode(), L.dnas_fastseqs_seq(h, i).decode())
+           for i in range(L.dnas_fastseqs_count(h))]
+    L.dnas_fastseqs_free(h)
+    return out
+
+
+def decode_fastseqs(filename, machine, params, device=0):
+    """decodeFastSeqs(filename, machine, params) (viterbi.cpp:306-320) -> [(name, decoded symbols, loglike)]."""
+    h = ctypes.c_void_p()
+    _l.check(_l.lib().dnas_decode_fastseqs(str(filename).encode(), machine._h, ctypes.byref(params.c), int(device),
+                                           ctypes.byref(h)))
+    L = _l.lib()
+    out = [(L.dnas_decoded_name(h, i).decode(), L.dnas_decoded_seq(h, i).decode(), L.dnas_decoded_loglike(h, i))
+           for i in range(L.dnas_decoded_count(h))]
+    L.dnas_decoded_free(h)
+    return out

@@ -1,0 +1,228 @@
+// Host-only half of the C ABI (include/dnastore_amd.h): file formats, flattening and the
+// decodeFastSeqs convenience call.  The device half lives in runtime.hip.
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/dnastore_amd.h"
+#include "errors.hpp"
+#include "host/encoder.hpp"
+#include "host/fastseq.hpp"
+#include "host/machine.hpp"
+#include "host/model.hpp"
+
+struct dnas_machine { dnas::Machine machine; };
+struct dnas_flat { dnas::FlatModel flat; };
+struct dnas_fastseqs { std::vector<dnas::FastSeq> seqs; };
+struct dnas_decoded {
+  std::vector<dnas::FastSeq> seqs;
+  std::vector<double> loglike;
+};
+
+namespace dnas {
+std::string& lastErrorSlot() {
+  thread_local std::string slot;
+  return slot;
+}
+}  // namespace dnas
+
+namespace {
+
+// Map the host layer's exceptions to ABI status codes (reference behaviour in comments).
+template <class F>
+int guarded(F&& body) {
+  try {
+    return body();
+  } catch (const std::domain_error& e) {  // cyclic null graph, trans.cpp:631-632
+    return dnas::fail(DNAS_E_CYCLIC, e.what());
+  } catch (const std::bad_alloc&) {
+    return dnas::fail(DNAS_E_NOMEM, "out of memory");
+  } catch (const std::exception& e) {
+    const std::string w = e.what();
+    int code = DNAS_E_PARSE;
+    if (w.rfind("File not found", 0) == 0 || w.rfind("Couldn't open", 0) == 0) code = DNAS_E_IO;  // Fail -> exit(1)
+    else if (w.rfind("Not a DNA-outputting machine", 0) == 0) code = DNAS_E_NOT_DNA;
+    else if (w.rfind("Unknown symbol", 0) == 0) code = DNAS_E_BAD_BASE;
+    return dnas::fail(code, w);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dnas_last_error(void) { return dnas::lastErrorSlot().c_str(); }
+void dnas_free(void* p) { free(p); }
+
+int dnas_machine_load_json(const char* path, dnas_machine** out) {
+  if (!path || !out) return dnas::fail(DNAS_E_INVALID, "null argument");
+  *out = nullptr;
+  return guarded([&] {
+    *out = new dnas_machine{dnas::Machine::fromFile(path)};
+    return DNAS_OK;
+  });
+}
+
+int dnas_machine_parse_json(const char* text, size_t len, dnas_machine** out) {
+  if (!text || !out) return dnas::fail(DNAS_E_INVALID, "null argument");
+  *out = nullptr;
+  return guarded([&] {
+    *out = new dnas_machine{dnas::Machine::fromJSON(std::string(text, len))};
+    return DNAS_OK;
+  });
+}
+
+void dnas_machine_free(dnas_machine* m) { delete m; }
+int32_t dnas_machine_n_states(const dnas_machine* m) { return m ? (int32_t)m->machine.nStates() : 0; }
+
+int dnas_machine_write_json(const dnas_machine* m, char** out_text, size_t* out_len) {
+  if (!m || !out_text || !out_len) return dnas::fail(DNAS_E_INVALID, "null argument");
+  return guarded([&] {
+    std::ostringstream ss;
+    m->machine.writeJSON(ss);
+    const std::string s = ss.str();
+    char* buf = (char*)malloc(s.size() + 1);
+    if (!buf) throw std::bad_alloc();
+    memcpy(buf, s.c_str(), s.size() + 1);
+    *out_text = buf;
+    *out_len = s.size();
+    return DNAS_OK;
+  });
+}
+
+static int encoded_to_c(dnas::Encoder& enc, char** out_dna, size_t* out_len) {
+  enc.close();
+  const std::string& s = enc.output();
+  char* buf = (char*)malloc(s.size() + 1);
+  if (!buf) throw std::bad_alloc();
+  memcpy(buf, s.c_str(), s.size() + 1);
+  *out_dna = buf;
+  *out_len = s.size();
+  return DNAS_OK;
+}
+
+int dnas_encode_symbols(const dnas_machine* m, const char* symbols, size_t n, char** out_dna, size_t* out_len) {
+  if (!m || (!symbols && n) || !out_dna || !out_len) return dnas::fail(DNAS_E_INVALID, "null argument");
+  return guarded([&] {
+    dnas::Encoder enc(m->machine);
+    enc.encodeSymbolString(std::string(symbols, n));
+    return encoded_to_c(enc, out_dna, out_len);
+  });
+}
+
+int dnas_encode_bytes(const dnas_machine* m, const uint8_t* bytes, size_t n, char** out_dna, size_t* out_len) {
+  if (!m || (!bytes && n) || !out_dna || !out_len) return dnas::fail(DNAS_E_INVALID, "null argument");
+  return guarded([&] {
+    dnas::Encoder enc(m->machine);
+    enc.encodeBytes(std::string((const char*)bytes, n));
+    return encoded_to_c(enc, out_dna, out_len);
+  });
+}
+
+int dnas_mutator_params_from_flags(double sub_prob, double iv_ratio, double dup_prob, double del_open, double del_ext,
+                                   int global, int length, dnas_mutator_params* out) {
+  if (!out) return dnas::fail(DNAS_E_INVALID, "null argument");
+  return guarded([&] {
+    dnas::MutatorParams::fromFlags(sub_prob, iv_ratio, dup_prob, del_open, del_ext, global != 0, length).toC(out);
+    return DNAS_OK;
+  });
+}
+
+int dnas_mutator_params_load_json(const char* path, dnas_mutator_params* out) {
+  if (!path || !out) return dnas::fail(DNAS_E_INVALID, "null argument");
+  return guarded([&] {
+    dnas::MutatorParams::fromFile(path).toC(out);
+    return DNAS_OK;
+  });
+}
+
+int dnas_flatten(const dnas_machine* m, const dnas_mutator_params* p, dnas_flat** out) {
+  if (!m || !p || !out) return dnas::fail(DNAS_E_INVALID, "null argument");
+  *out = nullptr;
+  return guarded([&] {
+    dnas_flat* f = new dnas_flat{dnas::FlatModel::build(m->machine, dnas::MutatorParams::fromC(*p))};
+    f->flat.bind();
+    *out = f;
+    return DNAS_OK;
+  });
+}
+
+const dnas_flat_model* dnas_flat_view(const dnas_flat* f) { return f ? &f->flat.view : nullptr; }
+void dnas_flat_free(dnas_flat* f) { delete f; }
+
+int dnas_fastseqs_read(const char* path, dnas_fastseqs** out) {
+  if (!path || !out) return dnas::fail(DNAS_E_INVALID, "null argument");
+  *out = nullptr;
+  return guarded([&] {
+    *out = new dnas_fastseqs{dnas::readFastSeqs(path)};
+    return DNAS_OK;
+  });
+}
+int64_t dnas_fastseqs_count(const dnas_fastseqs* f) { return f ? (int64_t)f->seqs.size() : 0; }
+const char* dnas_fastseqs_name(const dnas_fastseqs* f, int64_t i) { return f->seqs[(size_t)i].name.c_str(); }
+const char* dnas_fastseqs_seq(const dnas_fastseqs* f, int64_t i) { return f->seqs[(size_t)i].seq.c_str(); }
+void dnas_fastseqs_free(dnas_fastseqs* f) { delete f; }
+
+// decodeFastSeqs (viterbi.cpp:306-320): read the FASTA, build the input model once,
+// decode every read on the GPU, keep names, drop comments.
+int dnas_decode_fastseqs(const char* fasta_path, const dnas_machine* m, const dnas_mutator_params* p, int device_id,
+                         dnas_decoded** out) {
+  if (!fasta_path || !m || !p || !out) return dnas::fail(DNAS_E_INVALID, "null argument");
+  *out = nullptr;
+  dnas_flat* flat = nullptr;
+  dnas_model* model = nullptr;
+  int rc = guarded([&] {
+    const std::vector<dnas::FastSeq> reads = dnas::readFastSeqs(fasta_path);
+    int r = dnas_flatten(m, p, &flat);
+    if (r != DNAS_OK) return r;
+    std::vector<uint64_t> off{0}, outOff{0};
+    std::vector<uint8_t> bases;
+    for (const auto& fs : reads) {
+      const std::vector<uint8_t> tok = dnas::tokenizeDNA(fs.seq, fs.name);
+      bases.insert(bases.end(), tok.begin(), tok.end());
+      off.push_back(bases.size());
+      outOff.push_back(outOff.back() + 4 * tok.size() + 64);
+    }
+    dnas_decoded* d = new dnas_decoded();
+    const int64_t n = (int64_t)reads.size();
+    if (n > 0) {
+      r = dnas_model_create(dnas_flat_view(flat), device_id, 0, &model);
+      if (r != DNAS_OK) { delete d; return r; }
+      std::vector<char> sym(outOff.back());
+      std::vector<uint32_t> len(n);
+      std::vector<double> ll(n);
+      std::vector<uint8_t> st(n);
+      if (bases.empty()) bases.push_back(0);
+      r = dnas_viterbi_batch(model, n, off.data(), bases.data(), sym.data(), outOff.data(), len.data(), ll.data(), st.data());
+      if (r != DNAS_OK) { delete d; return r; }
+      for (int64_t i = 0; i < n; ++i) {
+        if (st[i] == DNAS_READ_OUT_OVERFLOW || st[i] == DNAS_READ_TRACEBACK_FAIL) {
+          delete d;
+          return dnas::fail(DNAS_E_DEVICE, st[i] == DNAS_READ_OUT_OVERFLOW ? "decoded string overflowed its slot"
+                                                                            : "Traceback failure");
+        }
+        dnas::FastSeq fs;
+        fs.name = reads[i].name;  // viterbi.cpp:315: name kept, comment dropped
+        fs.seq.assign(sym.data() + outOff[i], len[i]);
+        d->seqs.push_back(std::move(fs));
+        d->loglike.push_back(ll[i]);
+      }
+    }
+    *out = d;
+    return DNAS_OK;
+  });
+  if (model) dnas_model_destroy(model);
+  if (flat) dnas_flat_free(flat);
+  return rc;
+}
+
+int64_t dnas_decoded_count(const dnas_decoded* d) { return d ? (int64_t)d->seqs.size() : 0; }
+const char* dnas_decoded_name(const dnas_decoded* d, int64_t i) { return d->seqs[(size_t)i].name.c_str(); }
+const char* dnas_decoded_seq(const dnas_decoded* d, int64_t i) { return d->seqs[(size_t)i].seq.c_str(); }
+double dnas_decoded_loglike(const dnas_decoded* d, int64_t i) { return d->loglike[(size_t)i]; }
+void dnas_decoded_free(dnas_decoded* d) { delete d; }
+
+}  // extern "C"

@@ -1,0 +1,23 @@
+// Kernel-argument view of the flattened model (device pointers), shared by the
+// kernels (viterbi_kernels.hip) and the launcher (runtime.hip).
+#pragma once
+#include <stdint.h>
+
+constexpr int kFillThreads = 512;   // work-group size of viterbi_fill_kernel (8 waves)
+constexpr int kTraceThreads = 64;   // one wave of independent reads per traceback block
+constexpr int kMaxLen = 32;         // pLen entries (dnas_mutator_params.p_len)
+
+struct DevModel {
+  int N, Npad, D, P, local;
+  // in-edges per destination, reference enumeration order (traceback tie-break order)
+  const int32_t* einPtr; const int32_t* einSrc; const double* einScore; const uint8_t* einBase; const uint8_t* einIn;
+  const int32_t* ninPtr; const int32_t* ninSrc; const double* ninScore; const uint8_t* ninIn;
+  // out-edges per source (dirty marking)
+  const int32_t* eoutPtr; const int32_t* eoutDst;
+  const int32_t* noutPtr; const int32_t* noutDst;
+  const uint8_t* mdl;   // [N]
+  const uint8_t* ctx;   // [N*D]
+  double noGap, delOpen, delExtend, delEnd, tanDup;
+  double sub[16];
+  double len[kMaxLen];
+};

@@ -1,0 +1,326 @@
+// Device runtime behind the C ABI: model upload, lattice arena, batch scheduling and
+// kernel launches for the Viterbi path (include/dnastore_amd.h, "device side").
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/dnastore_amd.h"
+#include "device_model.h"
+#include "errors.hpp"
+
+extern "C" __global__ void viterbi_fill_kernel(DevModel, const uint8_t*, const uint64_t*, const int32_t*,
+                                               const uint64_t*, double*, double*, unsigned long long*, int);
+extern "C" __global__ void viterbi_traceback_kernel(DevModel, const uint8_t*, const uint64_t*, const int32_t*,
+                                                    const uint64_t*, const double*, char*, const uint64_t*,
+                                                    uint32_t*, uint8_t*, int);
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return dnas::fail(DNAS_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+  } while (0)
+
+struct dnas_model {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  DevModel dm{};
+  std::vector<void*> owned;   // device allocations of the tables
+  double* arena = nullptr;
+  size_t arenaBytes = 0, arenaCap = 0;
+  int maxSlots = 512;
+  unsigned long long* dRounds = nullptr;
+  // per-call scheduling arrays (device), grown on demand
+  int32_t* dBatchRead = nullptr;
+  uint64_t *dSlotOff = nullptr, *dReadOff = nullptr, *dOutOff = nullptr;
+  size_t schedCap = 0;
+  std::vector<uint64_t> lastSlotOff;   // host copy, sorted-batch order of the last call
+  std::vector<int32_t> lastBatchRead;
+  std::vector<hipEvent_t> events;      // 3 per batch: start, after fill, after traceback
+  dnas_batch_stats stats{};
+  bool statsPending = false;
+};
+
+namespace {
+
+template <class T>
+int upload(dnas_model* m, const T* host, size_t n, const T** out) {
+  T* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, std::max<size_t>(n, 1) * sizeof(T)));
+  m->owned.push_back(d);
+  if (n) HIP_TRY(hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice));
+  *out = d;
+  return DNAS_OK;
+}
+
+int collect_stats(dnas_model* m) {
+  if (!m->statsPending) return DNAS_OK;
+  m->stats.fill_ms = m->stats.traceback_ms = 0;
+  for (size_t i = 0; i + 3 <= m->events.size(); i += 3) {
+    float a = 0, b = 0;
+    HIP_TRY(hipEventElapsedTime(&a, m->events[i], m->events[i + 1]));
+    HIP_TRY(hipEventElapsedTime(&b, m->events[i + 1], m->events[i + 2]));
+    m->stats.fill_ms += a;
+    m->stats.traceback_ms += b;
+  }
+  unsigned long long r = 0;
+  HIP_TRY(hipMemcpy(&r, m->dRounds, sizeof r, hipMemcpyDeviceToHost));
+  m->stats.rounds = (int64_t)r;
+  m->statsPending = false;
+  return DNAS_OK;
+}
+
+}  // namespace
+
+extern "C" int dnas_has_device_code(void) { return 1; }
+
+extern "C" int dnas_model_create(const dnas_flat_model* fm, int device_id, size_t arena_bytes, dnas_model** out) {
+  if (!fm || !out) return dnas::fail(DNAS_E_INVALID, "dnas_model_create: null argument");
+  *out = nullptr;
+  if (fm->n_len > kMaxLen) return dnas::fail(DNAS_E_UNSUPPORTED, "pLen longer than 32 entries");
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return dnas::fail(DNAS_E_DEVICE, "no HIP device available");
+  if (device_id < 0 || device_id >= count) return dnas::fail(DNAS_E_INVALID, "device_id out of range");
+  HIP_TRY(hipSetDevice(device_id));
+  dnas_model* m = new dnas_model();
+  m->device = device_id;
+  auto bail = [&](int rc) { dnas_model_destroy(m); return rc; };
+  if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess)
+    return bail(dnas::fail(DNAS_E_DEVICE, "hipStreamCreate failed"));
+  const int N = fm->n_states, D = fm->max_dup_len;
+  DevModel& d = m->dm;
+  d.N = N;
+  d.Npad = (N + 31) & ~31;  // 256-byte aligned rows
+  d.D = D;
+  d.P = fm->n_len;
+  d.local = fm->local;
+  int rc;
+#define UP(field, src, n) if ((rc = upload(m, src, (size_t)(n), &d.field)) != DNAS_OK) return bail(rc)
+  UP(einPtr, fm->ein_ptr, N + 1); UP(einSrc, fm->ein_src, fm->n_emit); UP(einScore, fm->ein_score, fm->n_emit);
+  UP(einBase, fm->ein_base, fm->n_emit); UP(einIn, fm->ein_in, fm->n_emit);
+  UP(ninPtr, fm->nin_ptr, N + 1); UP(ninSrc, fm->nin_src, fm->n_null); UP(ninScore, fm->nin_score, fm->n_null);
+  UP(ninIn, fm->nin_in, fm->n_null);
+  UP(eoutPtr, fm->eout_ptr, N + 1); UP(eoutDst, fm->eout_dst, fm->n_emit);
+  UP(noutPtr, fm->nout_ptr, N + 1); UP(noutDst, fm->nout_dst, fm->n_null);
+  UP(mdl, fm->mdl, N); UP(ctx, fm->ctx, (size_t)N * (D ? D : 1));
+#undef UP
+  d.noGap = fm->no_gap; d.delOpen = fm->del_open; d.delExtend = fm->del_extend; d.delEnd = fm->del_end;
+  d.tanDup = fm->tan_dup;
+  memcpy(d.sub, fm->sub, sizeof d.sub);
+  for (int k = 0; k < kMaxLen; ++k) d.len[k] = k < fm->n_len ? fm->len[k] : 0.;
+  if (hipMalloc((void**)&m->dRounds, sizeof(unsigned long long)) != hipSuccess)
+    return bail(dnas::fail(DNAS_E_DEVICE, "hipMalloc failed"));
+  size_t freeB = 0, totalB = 0;
+  if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return bail(dnas::fail(DNAS_E_DEVICE, "hipMemGetInfo failed"));
+  m->arenaCap = arena_bytes ? arena_bytes : (size_t)((double)freeB * 0.6);
+  if (const char* s = getenv("DNAS_MAX_SLOTS")) m->maxSlots = std::max(1, atoi(s));
+  *out = m;
+  return DNAS_OK;
+}
+
+extern "C" void dnas_model_destroy(dnas_model* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->device);
+  if (m->stream) (void)hipStreamSynchronize(m->stream);
+  for (void* p : m->owned) (void)hipFree(p);
+  if (m->arena) (void)hipFree(m->arena);
+  if (m->dRounds) (void)hipFree(m->dRounds);
+  if (m->dBatchRead) (void)hipFree(m->dBatchRead);
+  if (m->dSlotOff) (void)hipFree(m->dSlotOff);
+  if (m->dReadOff) (void)hipFree(m->dReadOff);
+  if (m->dOutOff) (void)hipFree(m->dOutOff);
+  for (hipEvent_t e : m->events) (void)hipEventDestroy(e);
+  if (m->stream) (void)hipStreamDestroy(m->stream);
+  delete m;
+}
+
+extern "C" int dnas_model_sync(dnas_model* m) {
+  if (!m) return dnas::fail(DNAS_E_INVALID, "null model");
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  return collect_stats(m);
+}
+
+extern "C" int dnas_model_last_stats(const dnas_model* m, dnas_batch_stats* out) {
+  if (!m || !out) return dnas::fail(DNAS_E_INVALID, "null argument");
+  if (m->statsPending) return dnas::fail(DNAS_E_INVALID, "call dnas_model_sync first");
+  *out = m->stats;
+  return DNAS_OK;
+}
+
+extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const uint64_t* read_offsets,
+                                         const uint8_t* d_bases, char* d_out_sym, const uint64_t* out_offsets,
+                                         uint32_t* d_out_len, double* d_out_loglike, uint8_t* d_out_status) {
+  if (!m || n_reads < 0 || (n_reads > 0 && (!read_offsets || !d_bases || !d_out_sym || !out_offsets || !d_out_len ||
+                                            !d_out_loglike || !d_out_status)))
+    return dnas::fail(DNAS_E_INVALID, "dnas_viterbi_batch_device: bad argument");
+  HIP_TRY(hipSetDevice(m->device));
+  // the previous call's events/stat buffers are about to be reused
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  m->stats = dnas_batch_stats{};
+  m->statsPending = false;
+  if (n_reads == 0) return DNAS_OK;
+  const DevModel& d = m->dm;
+  const size_t lanes = (size_t)d.D + 2;
+  const size_t colDoubles = lanes * (size_t)d.Npad;
+
+  // longest reads first: a batch's work-groups then finish together
+  std::vector<int32_t> order((size_t)n_reads);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+    return read_offsets[a + 1] - read_offsets[a] > read_offsets[b + 1] - read_offsets[b];
+  });
+  const size_t arenaCapDoubles = m->arenaCap / sizeof(double);
+  std::vector<uint64_t> slotOff((size_t)n_reads);
+  std::vector<int64_t> batchStart{0};
+  size_t used = 0, peak = 0;
+  int64_t columns = 0;
+  for (int64_t i = 0; i < n_reads; ++i) {
+    const uint64_t L = read_offsets[order[i] + 1] - read_offsets[order[i]];
+    if (L > 0x7ffffff0ull) return dnas::fail(DNAS_E_UNSUPPORTED, "read too long");
+    const size_t need = colDoubles * (size_t)(L + 1);
+    if (need > arenaCapDoubles)
+      return dnas::fail(DNAS_E_NOMEM, "a single read's lattice (" + std::to_string(need * 8) +
+                                          " bytes) exceeds the lattice arena (" + std::to_string(m->arenaCap) + ")");
+    if (i - batchStart.back() >= m->maxSlots || used + need > arenaCapDoubles) {
+      batchStart.push_back(i);
+      used = 0;
+    }
+    slotOff[i] = used;
+    used += need;
+    peak = std::max(peak, used);
+    columns += (int64_t)L + 1;
+  }
+  batchStart.push_back(n_reads);
+  if (peak * sizeof(double) > m->arenaBytes) {
+    if (m->arena) HIP_TRY(hipFree(m->arena));
+    m->arena = nullptr;
+    m->arenaBytes = 0;
+    HIP_TRY(hipMalloc((void**)&m->arena, peak * sizeof(double)));
+    m->arenaBytes = peak * sizeof(double);
+  }
+  if ((size_t)n_reads + 1 > m->schedCap) {
+    if (m->dBatchRead) { (void)hipFree(m->dBatchRead); (void)hipFree(m->dSlotOff); (void)hipFree(m->dReadOff); (void)hipFree(m->dOutOff); }
+    m->dBatchRead = nullptr; m->dSlotOff = m->dReadOff = m->dOutOff = nullptr;
+    m->schedCap = 0;
+    const size_t cap = (size_t)n_reads + 1;
+    HIP_TRY(hipMalloc((void**)&m->dBatchRead, cap * sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void**)&m->dSlotOff, cap * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc((void**)&m->dReadOff, cap * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc((void**)&m->dOutOff, cap * sizeof(uint64_t)));
+    m->schedCap = cap;
+  }
+  m->lastSlotOff = slotOff;
+  m->lastBatchRead = order;
+  // host vectors stay alive until the copies complete (synchronous copies keep this simple)
+  HIP_TRY(hipMemcpy(m->dBatchRead, order.data(), (size_t)n_reads * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(m->dSlotOff, slotOff.data(), (size_t)n_reads * sizeof(uint64_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(m->dReadOff, read_offsets, ((size_t)n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(m->dOutOff, out_offsets, ((size_t)n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemsetAsync(m->dRounds, 0, sizeof(unsigned long long), m->stream));
+
+  const size_t nBatches = batchStart.size() - 1;
+  while (m->events.size() < 3 * nBatches) {
+    hipEvent_t e;
+    HIP_TRY(hipEventCreate(&e));
+    m->events.push_back(e);
+  }
+  const int maskWords = (d.N + 31) / 32 + 1;
+  const size_t ldsBytes = 2 * (size_t)maskWords * sizeof(unsigned);
+  for (size_t b = 0; b < nBatches; ++b) {
+    const int64_t s = batchStart[b];
+    const int nB = (int)(batchStart[b + 1] - s);
+    HIP_TRY(hipEventRecord(m->events[3 * b], m->stream));
+    hipLaunchKernelGGL(viterbi_fill_kernel, dim3(nB), dim3(kFillThreads), ldsBytes, m->stream, d, d_bases,
+                       (const uint64_t*)m->dReadOff, (const int32_t*)(m->dBatchRead + s),
+                       (const uint64_t*)(m->dSlotOff + s), m->arena, d_out_loglike, m->dRounds, maskWords);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(m->events[3 * b + 1], m->stream));
+    hipLaunchKernelGGL(viterbi_traceback_kernel, dim3((nB + kTraceThreads - 1) / kTraceThreads), dim3(kTraceThreads), 0,
+                       m->stream, d, d_bases, (const uint64_t*)m->dReadOff, (const int32_t*)(m->dBatchRead + s),
+                       (const uint64_t*)(m->dSlotOff + s), (const double*)m->arena, d_out_sym,
+                       (const uint64_t*)m->dOutOff, d_out_len, d_out_status, nB);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(m->events[3 * b + 2], m->stream));
+  }
+  // trim so collect_stats sees exactly this call's events
+  while (m->events.size() > 3 * nBatches) {
+    (void)hipEventDestroy(m->events.back());
+    m->events.pop_back();
+  }
+  m->stats.fill_launches = (int64_t)nBatches;
+  m->stats.columns = columns;
+  m->stats.lattice_bytes = (int64_t)(8 * lanes * (size_t)d.N) * columns;
+  m->statsPending = true;
+  return DNAS_OK;
+}
+
+extern "C" int dnas_viterbi_batch(dnas_model* m, int64_t n_reads, const uint64_t* read_offsets, const uint8_t* bases,
+                                  char* out_sym, const uint64_t* out_offsets, uint32_t* out_len, double* out_loglike,
+                                  uint8_t* out_status) {
+  if (!m || n_reads < 0) return dnas::fail(DNAS_E_INVALID, "dnas_viterbi_batch: bad argument");
+  if (n_reads == 0) return DNAS_OK;
+  if (!read_offsets || !bases || !out_sym || !out_offsets || !out_len || !out_loglike || !out_status)
+    return dnas::fail(DNAS_E_INVALID, "dnas_viterbi_batch: null argument");
+  HIP_TRY(hipSetDevice(m->device));
+  const size_t nBases = (size_t)(read_offsets[n_reads] - read_offsets[0]);
+  if (read_offsets[0] != 0) return dnas::fail(DNAS_E_INVALID, "read_offsets[0] must be 0");
+  for (size_t i = 0; i < nBases; ++i)
+    if (bases[i] > 3) return dnas::fail(DNAS_E_BAD_BASE, "base code > 3 at offset " + std::to_string(i));
+  const size_t nOut = (size_t)out_offsets[n_reads];
+  uint8_t* dBases = nullptr; char* dSym = nullptr; uint32_t* dLen = nullptr; double* dLL = nullptr; uint8_t* dSt = nullptr;
+  int rc = DNAS_OK;
+  auto cleanup = [&]() {
+    if (dBases) (void)hipFree(dBases);
+    if (dSym) (void)hipFree(dSym);
+    if (dLen) (void)hipFree(dLen);
+    if (dLL) (void)hipFree(dLL);
+    if (dSt) (void)hipFree(dSt);
+  };
+#define TRY_OR_CLEAN(expr)                                                                                        \
+  do {                                                                                                            \
+    hipError_t e_ = (expr);                                                                                       \
+    if (e_ != hipSuccess) { cleanup(); return dnas::fail(DNAS_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } \
+  } while (0)
+  TRY_OR_CLEAN(hipMalloc((void**)&dBases, std::max<size_t>(nBases, 1)));
+  TRY_OR_CLEAN(hipMalloc((void**)&dSym, std::max<size_t>(nOut, 1)));
+  TRY_OR_CLEAN(hipMalloc((void**)&dLen, (size_t)n_reads * sizeof(uint32_t)));
+  TRY_OR_CLEAN(hipMalloc((void**)&dLL, (size_t)n_reads * sizeof(double)));
+  TRY_OR_CLEAN(hipMalloc((void**)&dSt, (size_t)n_reads));
+  if (nBases) TRY_OR_CLEAN(hipMemcpy(dBases, bases, nBases, hipMemcpyHostToDevice));
+  rc = dnas_viterbi_batch_device(m, n_reads, read_offsets, dBases, dSym, out_offsets, dLen, dLL, dSt);
+  if (rc == DNAS_OK) rc = dnas_model_sync(m);
+  if (rc != DNAS_OK) { cleanup(); return rc; }
+  if (nOut) TRY_OR_CLEAN(hipMemcpy(out_sym, dSym, nOut, hipMemcpyDeviceToHost));
+  TRY_OR_CLEAN(hipMemcpy(out_len, dLen, (size_t)n_reads * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  TRY_OR_CLEAN(hipMemcpy(out_loglike, dLL, (size_t)n_reads * sizeof(double), hipMemcpyDeviceToHost));
+  TRY_OR_CLEAN(hipMemcpy(out_status, dSt, (size_t)n_reads, hipMemcpyDeviceToHost));
+#undef TRY_OR_CLEAN
+  cleanup();
+  return DNAS_OK;
+}
+
+extern "C" int dnas_model_read_lattice(dnas_model* m, int64_t slot, int64_t len, double* out) {
+  if (!m || !out || slot < 0 || (size_t)slot >= m->lastSlotOff.size() || len < 0)
+    return dnas::fail(DNAS_E_INVALID, "dnas_model_read_lattice: bad argument");
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  const DevModel& d = m->dm;
+  const size_t lanes = (size_t)d.D + 2;
+  // `slot` indexes the caller's read order; find its arena slot
+  size_t pos = 0;
+  for (; pos < m->lastBatchRead.size(); ++pos)
+    if (m->lastBatchRead[pos] == (int32_t)slot) break;
+  if (pos == m->lastBatchRead.size()) return dnas::fail(DNAS_E_INVALID, "no such read in the last batch");
+  const double* src = m->arena + m->lastSlotOff[pos];
+  // strip the row padding: [pos][lane][Npad] -> [pos][lane][N]
+  HIP_TRY(hipMemcpy2D(out, (size_t)d.N * sizeof(double), src, (size_t)d.Npad * sizeof(double),
+                      (size_t)d.N * sizeof(double), (size_t)(len + 1) * lanes, hipMemcpyDeviceToHost));
+  return DNAS_OK;
+}

@@ -1,0 +1,282 @@
+// Hand-written gfx950 kernels for the Viterbi error decoder.
+//
+//   viterbi_fill_kernel       replaces the ViterbiMatrix constructor's lattice fill
+//                             (reference src/viterbi.cpp:62-176)
+//   viterbi_traceback_kernel  replaces ViterbiMatrix::traceback (src/viterbi.cpp:195-304)
+//
+// One work-group per read.  The lattice lives in HBM as [pos][lane][state] fp64
+// (lanes S, D, T1..TD; the reference's AoS [pos][state][lane], viterbi.h:65-67, turned
+// SoA so that every lane of a column is one coalesced stream).  The current column's S
+// and D rows double as the working storage of the in-column max-plus fixpoint.
+//
+// All arithmetic is fp64 max/+ in the reference's operand order; no contraction, no
+// fast-math (build with -ffp-contract=off).  max() is spelled (a < b ? b : a) == std::max.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_model.h"
+
+namespace {
+
+__device__ __forceinline__ double dmax(double a, double b) { return a < b ? b : a; }
+
+constexpr double kNegInf = -__builtin_huge_val();
+
+// Pull relaxation of one state inside the current column (the body of the reference's
+// worklist loop, viterbi.cpp:112-158, seen from the destination side):
+//   D(j) = max( D(j), max(D(src)+delExtend, S(src)+delOpen) + score   over emit-in,
+//                     D(src)+score                                    over null-in )
+//   S(j) = max( S(j), S(src)+score over null-in, D(j)+delEnd )
+// Returns true when either cell grew.
+__device__ __forceinline__ bool pull_state(const DevModel& m, int j, double* __restrict__ S, double* __restrict__ D) {
+  const double d0 = D[j], s0 = S[j];
+  double d = d0, s = s0;
+  const int eb = m.einPtr[j], ee = m.einPtr[j + 1];
+  for (int e = eb; e < ee; ++e) {
+    const int src = m.einSrc[e];
+    const double cand = dmax(D[src] + m.delExtend, S[src] + m.delOpen) + m.einScore[e];
+    d = dmax(d, cand);
+  }
+  const int nb = m.ninPtr[j], ne = m.ninPtr[j + 1];
+  for (int e = nb; e < ne; ++e) {
+    const int src = m.ninSrc[e];
+    const double sc = m.ninScore[e];
+    d = dmax(d, D[src] + sc);
+    s = dmax(s, S[src] + sc);
+  }
+  s = dmax(s, d + m.delEnd);
+  bool grew = false;
+  if (d > d0) { D[j] = d; grew = true; }
+  if (s > s0) { S[j] = s; grew = true; }
+  return grew;
+}
+
+// Mark every out-neighbour of j dirty for the next round.
+__device__ __forceinline__ void mark_successors(const DevModel& m, int j, unsigned* maskNext) {
+  const int eb = m.eoutPtr[j], ee = m.eoutPtr[j + 1];
+  for (int e = eb; e < ee; ++e) {
+    const int d = m.eoutDst[e];
+    atomicOr(&maskNext[d >> 5], 1u << (d & 31));
+  }
+  const int nb = m.noutPtr[j], ne = m.noutPtr[j + 1];
+  for (int e = nb; e < ne; ++e) {
+    const int d = m.noutDst[e];
+    atomicOr(&maskNext[d >> 5], 1u << (d & 31));
+  }
+}
+
+}  // namespace
+
+// grid = reads in this batch, block = kFillThreads.
+// Dynamic LDS: two dirty-state bitmasks of maskWords 32-bit words each.
+extern "C" __global__ void __launch_bounds__(kFillThreads)
+viterbi_fill_kernel(DevModel m, const uint8_t* __restrict__ bases, const uint64_t* __restrict__ readOff,
+                    const int32_t* __restrict__ batchRead, const uint64_t* __restrict__ slotOff,
+                    double* __restrict__ arena, double* __restrict__ outLoglike,
+                    unsigned long long* __restrict__ roundsTotal, int maskWords) {
+  extern __shared__ unsigned ldsMask[];
+  __shared__ double redBuf[kFillThreads / 64];
+  const int tid = threadIdx.x;
+  const int T = blockDim.x;
+  const int N = m.N, D_ = m.D, lanes = m.D + 2;
+  const size_t Npad = (size_t)m.Npad;
+  const int read = batchRead[blockIdx.x];
+  const uint8_t* seq = bases + readOff[read];
+  const int L = (int)(readOff[read + 1] - readOff[read]);
+  double* lat = arena + slotOff[blockIdx.x];
+  unsigned* mask0 = ldsMask;
+  unsigned* mask1 = ldsMask + maskWords;
+  const int maskBytes = (N + 7) >> 3;
+  unsigned rounds = 0;
+
+  for (int w = tid; w < 2 * maskWords; w += T) ldsMask[w] = 0;
+  __syncthreads();
+
+  for (int pos = 0; pos <= L; ++pos) {
+    double* col = lat + (size_t)pos * lanes * Npad;
+    double* S = col;
+    double* Dc = col + Npad;
+    const double* prev = col - (size_t)lanes * Npad;  // valid for pos > 0
+    const int x = pos > 0 ? seq[pos - 1] : 0;
+
+    // ---- phase A: S from the previous column (viterbi.cpp:92-95,101-103); D = -inf
+    for (int j = tid; j < N; j += T) {
+      double s;
+      if (pos == 0) {
+        s = (m.local || j == 0) ? 0. : kNegInf;  // viterbi.cpp:75-79
+      } else {
+        s = kNegInf;
+        const int eb = m.einPtr[j], ee = m.einPtr[j + 1];
+        for (int e = eb; e < ee; ++e)
+          s = dmax(s, ((prev[m.einSrc[e]] + m.einScore[e]) + m.noGap) + m.sub[m.einBase[e] * 4 + x]);
+        if (m.mdl[j] > 0) s = dmax(s, prev[2 * Npad + j] + m.sub[m.ctx[(size_t)j * D_] * 4 + x]);
+      }
+      S[j] = s;
+      Dc[j] = kNegInf;
+    }
+    __syncthreads();
+
+    // ---- phase B: in-column fixpoint (viterbi.cpp:97-99,110-159).  Round 1 visits every
+    // state (the reference seeds its worklist with all of them); later rounds visit the
+    // states whose predecessors grew.  Monotone max-plus => the least fixpoint reached is
+    // independent of the visiting order.
+    unsigned* cur = mask0;
+    unsigned* nxt = mask1;
+    {
+      int marked = 0;
+      for (int j = tid; j < N; j += T)
+        if (pull_state(m, j, S, Dc)) { mark_successors(m, j, nxt); marked = 1; }
+      ++rounds;
+      int more = __syncthreads_or(marked);
+      while (more) {
+        unsigned* t = cur; cur = nxt; nxt = t;
+        marked = 0;
+        uint8_t* curBytes = reinterpret_cast<uint8_t*>(cur);
+        for (int b = tid; b < maskBytes; b += T) {
+          unsigned bits = curBytes[b];
+          if (!bits) continue;
+          curBytes[b] = 0;
+          while (bits) {
+            const int j = (b << 3) + __builtin_ctz(bits);
+            bits &= bits - 1;
+            if (pull_state(m, j, S, Dc)) { mark_successors(m, j, nxt); marked = 1; }
+          }
+        }
+        ++rounds;
+        more = __syncthreads_or(marked);
+      }
+    }
+
+    // ---- phase C: duplication lanes (viterbi.cpp:105-106,161-168)
+    for (int j = tid; j < N; j += T) {
+      const double s = S[j];
+      const int mdl = m.mdl[j];
+      for (int k = 0; k < D_; ++k) {
+        double t = kNegInf;
+        if (pos > 0 && k < mdl) {
+          if (k < mdl - 1) t = prev[(size_t)(3 + k) * Npad + j] + m.sub[m.ctx[(size_t)j * D_ + k + 1] * 4 + x];
+          t = dmax(t, (s + m.tanDup) + m.len[k]);
+        }
+        col[(size_t)(2 + k) * Npad + j] = t;
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- local mode: loglike = best end state (viterbi.cpp:171-173)
+  double* lastS = lat + (size_t)L * lanes * Npad;
+  if (m.local) {
+    double best = kNegInf;
+    for (int j = tid; j < N; j += T) best = dmax(best, lastS[j]);
+    for (int off = 32; off > 0; off >>= 1) best = dmax(best, __shfl_down(best, off, 64));
+    if ((tid & 63) == 0) redBuf[tid >> 6] = best;
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < T / 64; ++w) best = dmax(best, redBuf[w]);
+      lastS[N - 1] = best;
+      outLoglike[read] = best;
+    }
+  } else if (tid == 0) {
+    outLoglike[read] = lastS[N - 1];
+  }
+  if (tid == 0) atomicAdd(roundsTotal, (unsigned long long)rounds);
+}
+
+// One thread per read: the reference's sequential pointer chase, candidate order and
+// strict '>' tie-breaking included (viterbi.cpp:217-228,247-301).
+extern "C" __global__ void __launch_bounds__(kTraceThreads)
+viterbi_traceback_kernel(DevModel m, const uint8_t* __restrict__ bases, const uint64_t* __restrict__ readOff,
+                         const int32_t* __restrict__ batchRead, const uint64_t* __restrict__ slotOff,
+                         const double* __restrict__ arena, char* __restrict__ outSym,
+                         const uint64_t* __restrict__ outOff, uint32_t* __restrict__ outLen,
+                         uint8_t* __restrict__ outStatus, int nBatch) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nBatch) return;
+  const int read = batchRead[b];
+  const uint8_t* seq = bases + readOff[read];
+  const int L = (int)(readOff[read + 1] - readOff[read]);
+  const double* lat = arena + slotOff[b];
+  const int N = m.N, D_ = m.D, lanes = m.D + 2;
+  const size_t Npad = (size_t)m.Npad;
+  char* out = outSym + outOff[read];
+  const long cap = (long)(outOff[read + 1] - outOff[read]);
+  long n = 0;
+
+#define CELL(st, ps, ln) lat[((size_t)(ps) * lanes + (size_t)(ln)) * Npad + (size_t)(st)]
+  if (!(CELL(N - 1, L, 0) > kNegInf)) {  // viterbi.cpp:198-201
+    outLen[read] = 0;
+    outStatus[read] = 1;  // DNAS_READ_NO_PATH
+    return;
+  }
+  int state = N - 1, pos = L, mut = 0;
+  int bestState = 0, bestPos = 0, bestMut = 0;
+  double best;
+  bool found;
+  uint8_t bestIn;
+  uint8_t status = 0;
+
+#define INIT_BEST() { best = kNegInf; found = false; bestIn = 0; }
+#define UPDATE_BEST(ss, pp, mm, trans, insym) { \
+    const double sc_ = CELL(ss, pp, mm) + (trans); \
+    if (sc_ > best) { best = sc_; bestState = (ss); bestPos = (pp); bestMut = (mm); bestIn = (insym); found = true; } }
+#define CHECK_BEST() { \
+    const double exp_ = CELL(state, pos, mut); \
+    const double den_ = fabs(exp_) < 1e-6 ? 1. : exp_; \
+    if (!(fabs((best - exp_) / den_) < 1e-6) || !found) { status = 3; break; } \
+    state = bestState; pos = bestPos; mut = bestMut; }
+
+  do {  // single-pass block so CHECK_BEST can break out on failure
+    INIT_BEST();
+    if (m.local) { for (int s = 0; s < N; ++s) UPDATE_BEST(s, L, 0, 0., 0); }
+    else UPDATE_BEST(N - 1, L, 0, 0., 0);
+    CHECK_BEST();
+
+    while (pos >= 0 && state > 0) {
+      const int mdl = m.mdl[state];
+      const uint8_t* ctx = m.ctx + (size_t)state * D_;
+      INIT_BEST();
+      if (mut == 0) {
+        if (pos > 0) {
+          const int x = seq[pos - 1];
+          for (int e = m.einPtr[state]; e < m.einPtr[state + 1]; ++e)
+            UPDATE_BEST(m.einSrc[e], pos - 1, 0, (m.einScore[e] + m.noGap) + m.sub[m.einBase[e] * 4 + x], m.einIn[e]);
+        }
+        for (int e = m.ninPtr[state]; e < m.ninPtr[state + 1]; ++e)
+          UPDATE_BEST(m.ninSrc[e], pos, 0, m.ninScore[e], m.ninIn[e]);
+        UPDATE_BEST(state, pos, 1, m.delEnd, 0);
+        if (mdl > 0 && pos > 0) UPDATE_BEST(state, pos - 1, 2, m.sub[ctx[0] * 4 + seq[pos - 1]], 0);
+        if (pos == 0 && m.local) UPDATE_BEST(0, 0, 0, 0., 0);
+      } else if (mut == 1) {
+        for (int e = m.einPtr[state]; e < m.einPtr[state + 1]; ++e) {
+          UPDATE_BEST(m.einSrc[e], pos, 1, m.einScore[e] + m.delExtend, m.einIn[e]);
+          UPDATE_BEST(m.einSrc[e], pos, 0, m.einScore[e] + m.delOpen, m.einIn[e]);
+        }
+        for (int e = m.ninPtr[state]; e < m.ninPtr[state + 1]; ++e)
+          UPDATE_BEST(m.ninSrc[e], pos, 1, m.ninScore[e], m.ninIn[e]);
+      } else {
+        const int k = mut - 2;
+        if (k < mdl - 1) UPDATE_BEST(state, pos - 1, 2 + k + 1, m.sub[ctx[k + 1] * 4 + seq[pos - 1]], 0);
+        UPDATE_BEST(state, pos, 0, m.tanDup + m.len[k], 0);
+      }
+      CHECK_BEST();
+      if (bestIn) {  // trace.push_front (viterbi.cpp:299-300): fill the slot from its end
+        if (n < cap) out[cap - 1 - n] = (char)bestIn;
+        ++n;
+      }
+    }
+  } while (false);
+#undef CELL
+#undef INIT_BEST
+#undef UPDATE_BEST
+#undef CHECK_BEST
+
+  if (status == 0 && n > cap) status = 2;  // DNAS_READ_OUT_OVERFLOW
+  if (status != 0) {
+    outLen[read] = 0;
+    outStatus[read] = status;
+    return;
+  }
+  for (long k = 0; k < n; ++k) out[k] = out[cap - n + k];  // forward order, moved to the slot's front
+  outLen[read] = (uint32_t)n;
+  outStatus[read] = 0;
+}

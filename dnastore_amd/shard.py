@@ -1,0 +1,70 @@
+"""Read sharding across the GPUs of one node (one process per GPU, torch.distributed).
+
+Reads are independent DPs (reference: the serial loop of viterbi.cpp:312-318), so the
+path has no exchange step: rank 0 scatters the packed reads once (RCCL scatter over
+xGMI on GPUs, gloo on CPU for tests), every rank decodes its own shard, and the decoded
+symbol strings + log-likelihoods are gathered back.  No collective sits inside the DP.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def partition(lengths, world):
+    """Deal reads to ranks so that every rank gets the same count and a similar length mix:
+    sort by length (longest first) and deal round-robin.  Returns a list of index arrays."""
+    order = np.argsort(-np.asarray(lengths, dtype=np.int64), kind="stable")
+    return [np.sort(order[r::world]) for r in range(world)]
+
+
+def _dist_ready(world):
+    return world > 1 and dist.is_available() and dist.is_initialized()
+
+
+def scatter_reads(read_offsets, bases, world, rank, device):
+    """Rank 0 holds (read_offsets uint64[n+1], bases uint8[...]) for the whole job; every rank
+    returns its shard as (indices int64[k], offsets uint64[k+1], bases uint8 tensor on `device`).
+    With world == 1 nothing is communicated."""
+    if not _dist_ready(world):
+        t = torch.from_numpy(np.ascontiguousarray(bases)).to(device)
+        return np.arange(len(read_offsets) - 1, dtype=np.int64), np.asarray(read_offsets, dtype=np.uint64), t
+    meta = [None]
+    if rank == 0:
+        lengths = np.diff(read_offsets).astype(np.int64)
+        parts = partition(lengths, world)
+        shard_lens = [lengths[p] for p in parts]
+        pad = int(max(int(sl.sum()) for sl in shard_lens))
+        meta = [(parts, shard_lens, pad)]
+    dist.broadcast_object_list(meta, src=0)
+    parts, shard_lens, pad = meta[0]
+    recv = torch.empty(max(pad, 1), dtype=torch.uint8, device=device)
+    chunks = None
+    if rank == 0:
+        chunks = []
+        for p in parts:
+            buf = np.zeros(max(pad, 1), dtype=np.uint8)
+            pos = 0
+            for i in p:
+                seg = bases[int(read_offsets[i]):int(read_offsets[i + 1])]
+                buf[pos:pos + len(seg)] = seg
+                pos += len(seg)
+            chunks.append(torch.from_numpy(buf).to(device))
+    dist.scatter(recv, scatter_list=chunks, src=0)
+    off = np.zeros(len(parts[rank]) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(shard_lens[rank])
+    return parts[rank].astype(np.int64), off, recv
+
+
+def gather_results(sym, out_len, loglike, status, world, rank):
+    """Fixed-shape per-rank result tensors (sym uint8[k*cap], out_len/loglike/status [k]) ->
+    on rank 0 a list over ranks of the same tuples (None elsewhere).  Equal k on every rank."""
+    if not _dist_ready(world):
+        return [(sym, out_len, loglike, status)]
+    outs = []
+    for t in (sym, out_len, loglike, status):
+        bucket = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+        dist.gather(t, gather_list=bucket, dst=0)
+        outs.append(bucket)
+    if rank != 0:
+        return None
+    return [tuple(outs[f][r] for f in range(4)) for r in range(world)]

@@ -1,0 +1,186 @@
+/*
+ * dnastore_amd.h -- C ABI of the MI355X-native error decoder for ihh/dnastore.
+ *
+ * The reference has no FFI/plugin boundary: its Viterbi path is the C++ function
+ *   vguard<FastSeq> decodeFastSeqs(const char*, const Machine&, const MutatorParams&)
+ * (reference src/viterbi.h:108, src/viterbi.cpp:306-320) called from one arm of main
+ * (t/dnastore.cpp:217-223).  This header is the boundary a maintainer would bind in its
+ * place: plain pointers and sizes, opaque handles, int status returns, no exceptions,
+ * no torch types.  Each entry point names the reference interface it replaces.
+ *
+ * Threading: a handle is thread-compatible (one host thread / one GPU per handle).
+ * Every function returns DNAS_OK (0) or a negative DNAS_E_* code; dnas_last_error()
+ * returns the message of the calling thread's last failure.
+ */
+#ifndef DNASTORE_AMD_H
+#define DNASTORE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DNAS_OK 0
+#define DNAS_E_INVALID (-1)   /* bad argument                                              */
+#define DNAS_E_IO (-2)        /* file not found / unreadable  (reference: Fail -> exit(1))  */
+#define DNAS_E_PARSE (-3)     /* malformed JSON / FASTA / contexts (verifyContexts)         */
+#define DNAS_E_CYCLIC (-4)    /* "Transducer is cyclic, can't toposort" (trans.cpp:631-632) */
+#define DNAS_E_NOT_DNA (-5)   /* "Not a DNA-outputting machine" (viterbi.cpp:27-28)         */
+#define DNAS_E_BAD_BASE (-6)  /* non-ACGT read character (fastseq.cpp:30-35)                */
+#define DNAS_E_DEVICE (-7)    /* HIP runtime failure / no GPU / extension not built         */
+#define DNAS_E_NOMEM (-8)
+#define DNAS_E_UNSUPPORTED (-9)
+
+/* per-read status written by dnas_viterbi_batch */
+#define DNAS_READ_OK 0
+#define DNAS_READ_NO_PATH 1        /* loglike == -inf: empty string, "No valid Viterbi decoding found" (viterbi.cpp:198-201) */
+#define DNAS_READ_OUT_OVERFLOW 2   /* decoded string longer than the caller's slot            */
+#define DNAS_READ_TRACEBACK_FAIL 3 /* checkBest assertion (viterbi.cpp:230-237)               */
+
+typedef struct dnas_machine dnas_machine; /* Machine, reference src/trans.h:82-126 */
+typedef struct dnas_model dnas_model;     /* device-resident MachineScores + MutatorScores + InputModel */
+
+/* MutatorParams, reference src/mutator.h:9-31 */
+typedef struct dnas_mutator_params {
+  double p_del_open, p_del_extend, p_tan_dup, p_transition, p_transversion;
+  int32_t n_len;        /* pLen.size() = maxDupLen() */
+  int32_t local;        /* 1 = local (partial reads allowed), 0 = --error-global */
+  double p_len[32];
+} dnas_mutator_params;
+
+/*
+ * The flattened model: everything ViterbiMatrix derives from (Machine, MutatorParams)
+ * before touching a read -- InputModel (viterbi.cpp:6-14,309-310), MachineScores
+ * (viterbi.cpp:23-60), MutatorScores (mutator.cpp:56-75), decoderToposort
+ * (trans.cpp:604-634) -- as flat CSR arrays.  Edge order inside every row is the
+ * reference's enumeration order (ascending source state, then transition order), which
+ * is the traceback tie-break order.  All pointers are owned by the dnas_flat handle.
+ */
+typedef struct dnas_flat_model {
+  int32_t n_states;      /* N                                                   */
+  int32_t max_dup_len;   /* D = min(maxLeftContext, P), viterbi.cpp:63          */
+  int32_t n_len;         /* P                                                   */
+  int32_t local;
+  int32_t n_emit, n_null;
+  /* incoming edges per destination state */
+  const int32_t *ein_ptr, *ein_src;   const double *ein_score; const uint8_t *ein_in, *ein_base;
+  const int32_t *nin_ptr, *nin_src;   const double *nin_score; const uint8_t *nin_in;
+  /* outgoing edges per source state */
+  const int32_t *eout_ptr, *eout_dst; const double *eout_score;
+  const int32_t *nout_ptr, *nout_dst; const double *nout_score;
+  const uint8_t *mdl;                 /* [N]   maxDupLenAt, viterbi.h:104                      */
+  const uint8_t *ctx;                 /* [N*D] ctx[j*D+k] = tanDupBase(j,k), viterbi.h:105     */
+  const int32_t *topo;                /* [N]   decoderToposort order                           */
+  double no_gap, del_open, del_extend, del_end, tan_dup;
+  double sub[16];                     /* sub[base*4+observed]                                  */
+  const double *len;                  /* [P]                                                   */
+  char alphabet[64];                  /* inputAlphabet(Relaxed|Control|SEOF)                   */
+  double sym_logp[128];               /* log P(input symbol), 0 where absent                   */
+} dnas_flat_model;
+
+typedef struct dnas_flat dnas_flat;
+
+/* ---- host side: file formats (no GPU needed) ------------------------------------- */
+
+/* Machine::fromFile / readJSON (trans.cpp:431-482). */
+int dnas_machine_load_json(const char *path, dnas_machine **out);
+int dnas_machine_parse_json(const char *text, size_t len, dnas_machine **out);
+void dnas_machine_free(dnas_machine *m);
+int32_t dnas_machine_n_states(const dnas_machine *m);
+/* Machine::writeJSON (trans.cpp:402-429) into a malloc'd buffer the caller frees with dnas_free. */
+int dnas_machine_write_json(const dnas_machine *m, char **out_text, size_t *out_len);
+
+/* Exact encoder (reference Encoder<FastaWriter>, src/encoder.h:7-243): input symbols
+ * ('^', '0', '1', '$', controls ...; SOF/EOF are added when missing, as the reference does)
+ * or raw bytes (bits LSB first, encoder.h:222-231) -> DNA string, malloc'd, caller frees
+ * with dnas_free.  Makes synthetic reads for bench.py and the parity tests. */
+int dnas_encode_symbols(const dnas_machine *m, const char *symbols, size_t n_symbols, char **out_dna, size_t *out_len);
+int dnas_encode_bytes(const dnas_machine *m, const uint8_t *bytes, size_t n_bytes, char **out_dna, size_t *out_len);
+
+/* Error model from the CLI flags (t/dnastore.cpp:119-129): --error-sub-prob, --error-iv-ratio,
+ * --error-dup-prob, --error-del-open, --error-del-ext, --error-global, --length. */
+int dnas_mutator_params_from_flags(double sub_prob, double iv_ratio, double dup_prob, double del_open,
+                                   double del_ext, int global, int length, dnas_mutator_params *out);
+/* MutatorParams::fromFile (mutator.cpp:18-49), the --error-file format. */
+int dnas_mutator_params_load_json(const char *path, dnas_mutator_params *out);
+
+/* MachineScores + InputModel + MutatorScores + toposort, once per (machine, params). */
+int dnas_flatten(const dnas_machine *m, const dnas_mutator_params *p, dnas_flat **out);
+const dnas_flat_model *dnas_flat_view(const dnas_flat *f);
+void dnas_flat_free(dnas_flat *f);
+
+/* ---- device side ------------------------------------------------------------------ */
+
+/* Upload the flattened model to GPU `device_id` and size the lattice arena.
+ * arena_bytes = 0 picks a default (a fraction of free HBM). */
+int dnas_model_create(const dnas_flat_model *fm, int device_id, size_t arena_bytes, dnas_model **out);
+void dnas_model_destroy(dnas_model *model);
+
+/*
+ * The hot path: decodeFastSeqs' per-read loop (viterbi.cpp:312-318) for a batch.
+ *   read_offsets[n_reads+1]  prefix offsets into bases
+ *   bases[...]               one byte per nucleotide, values 0..3 (A,C,G,T)
+ *   out_sym                  caller buffer; read i's decoded symbols go to
+ *                            out_sym[out_offsets[i] .. out_offsets[i+1]) (no terminator)
+ *   out_len[n_reads]         decoded length (0 for DNAS_READ_NO_PATH)
+ *   out_loglike[n_reads]     ViterbiMatrix::loglike(), fp64 (viterbi.h:102)
+ *   out_status[n_reads]      DNAS_READ_*
+ * Host pointers; the call copies in, runs fill + traceback kernels, copies out, and
+ * returns after the stream has drained.
+ */
+int dnas_viterbi_batch(dnas_model *model, int64_t n_reads, const uint64_t *read_offsets, const uint8_t *bases,
+                       char *out_sym, const uint64_t *out_offsets, uint32_t *out_len, double *out_loglike,
+                       uint8_t *out_status);
+
+/* Same, with bases and all outputs already resident in this GPU's HBM (device pointers);
+ * read_offsets / out_offsets stay host arrays (they drive batching).  Asynchronous on the
+ * model's stream; dnas_model_sync waits. */
+int dnas_viterbi_batch_device(dnas_model *model, int64_t n_reads, const uint64_t *read_offsets,
+                              const uint8_t *d_bases, char *d_out_sym, const uint64_t *out_offsets,
+                              uint32_t *d_out_len, double *d_out_loglike, uint8_t *d_out_status);
+int dnas_model_sync(dnas_model *model);
+
+/* Device-time accounting of the last batch call (HIP events on the model's stream). */
+typedef struct dnas_batch_stats {
+  double fill_ms, traceback_ms;   /* summed kernel durations          */
+  int64_t fill_launches, columns; /* launches; sum over reads of L+1  */
+  int64_t lattice_bytes;          /* 8*(D+2)*N*columns (algorithmic)  */
+  int64_t rounds;                 /* relaxation rounds, summed        */
+} dnas_batch_stats;
+int dnas_model_last_stats(const dnas_model *model, dnas_batch_stats *out);
+
+/* Copy one read's lattice out of the arena after a single-read batch (testing aid):
+ * layout [pos][lane][n_states], lanes S, D, T1..TD. */
+int dnas_model_read_lattice(dnas_model *model, int64_t slot, int64_t len, double *out);
+
+/* ---- convenience: the whole reference call ------------------------------------------ */
+
+typedef struct dnas_decoded dnas_decoded; /* vguard<FastSeq> result of decodeFastSeqs */
+/* decodeFastSeqs(filename, machine, params) (viterbi.cpp:306-320) on GPU `device_id`. */
+int dnas_decode_fastseqs(const char *fasta_path, const dnas_machine *m, const dnas_mutator_params *p,
+                         int device_id, dnas_decoded **out);
+int64_t dnas_decoded_count(const dnas_decoded *d);
+const char *dnas_decoded_name(const dnas_decoded *d, int64_t i);
+const char *dnas_decoded_seq(const dnas_decoded *d, int64_t i);
+double dnas_decoded_loglike(const dnas_decoded *d, int64_t i);
+void dnas_decoded_free(dnas_decoded *d);
+
+/* FASTA/FASTQ(.gz) reader, readFastSeqs (fastseq.cpp:123-148): names + sequences. */
+typedef struct dnas_fastseqs dnas_fastseqs;
+int dnas_fastseqs_read(const char *path, dnas_fastseqs **out);
+int64_t dnas_fastseqs_count(const dnas_fastseqs *f);
+const char *dnas_fastseqs_name(const dnas_fastseqs *f, int64_t i);
+const char *dnas_fastseqs_seq(const dnas_fastseqs *f, int64_t i);
+void dnas_fastseqs_free(dnas_fastseqs *f);
+
+const char *dnas_last_error(void);
+void dnas_free(void *p);
+/* 1 when the library was built with its HIP kernels (always, for the shipped .so). */
+int dnas_has_device_code(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DNASTORE_AMD_H */

@@ -1,0 +1,125 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the
+reference's golden vectors.  Bit-exact: decoded strings, fp64 log-likelihoods and, on the
+small cases, every cell of the lattice."""
+import math
+import os
+import random
+
+import numpy as np
+import pytest
+
+from viterbi_cases import VITERBI_GOLDENS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def da():
+    import dnastore_amd
+    return dnastore_amd
+
+
+def _pair(da, O, ref_data, mach, flags):
+    path = os.path.join(ref_data, mach)
+    dec = da.ViterbiDecoder(da.Machine.fromFile(path), da.MutatorParams.fromFlags(**flags))
+    orc = O.ViterbiOracle(O.Machine.from_file(path), O.MutatorParams.from_cli(**flags))
+    return dec, orc
+
+
+@pytest.mark.parametrize("mach,fa,flags,bits,loglike", VITERBI_GOLDENS)
+def test_reference_goldens(da, oracle_mod, ref_data, mach, fa, flags, bits, loglike):
+    dec = da.ViterbiDecoder(da.Machine.fromFile(os.path.join(ref_data, mach)), da.MutatorParams.fromFlags(**flags))
+    want = open(os.path.join(ref_data, bits)).read().strip()
+    reads = [s for _, s in da.read_fastseqs(os.path.join(ref_data, fa))]
+    out, ll, st = dec.decode(reads)
+    assert out == [want] and st[0] == 0
+    assert ll[0] == loglike            # bit-exact fp64
+    dec.close()
+
+
+@pytest.mark.parametrize("mach,fa,flags", [
+    ("l4c4.json", "hello.dup.fa", dict(sub=0., del_open=0., global_=True)),
+    ("l4c4.json", "hello.fa", dict()),
+    ("h74l4c4.json", "hello.h74.sub.fa", dict()),
+    ("s16mr2l4c4.json", "hello.s16mr2.fa", dict(global_=True)),
+    ("s16h74l4c4.json", "hello.s16h74.del.fa", dict()),
+])
+def test_full_lattice_bit_exact(da, oracle_mod, ref_data, mach, fa, flags):
+    dec, orc = _pair(da, oracle_mod, ref_data, mach, flags)
+    read = da.read_fastseqs(os.path.join(ref_data, fa))[0][1]
+    out, ll, st = dec.decode([read])
+    s, oll, olat = orc.decode(read, want_lattice=True)      # [L+1][N][lanes]
+    lat = dec.lattice(0, len(read))                          # [L+1][lanes][N]
+    assert out[0] == s and ll[0] == oll
+    a = np.ascontiguousarray(lat.transpose(0, 2, 1))
+    assert a.shape == olat.shape
+    assert np.array_equal(a.view(np.uint64), olat.view(np.uint64))
+    dec.close()
+
+
+@pytest.mark.parametrize("flags,noise", [
+    (dict(global_=True), dict(sub=0.01)),
+    (dict(), dict(sub=0.02, dele=0.01, dup=0.01)),
+])
+def test_synthetic_batch_s16h74(da, oracle_mod, ref_data, flags, noise):
+    from synth import synthetic_reads
+    dec, orc = _pair(da, oracle_mod, ref_data, "s16h74l4c4.json", flags)
+    reads = synthetic_reads(orc.machine, 6, 6, seed=1000, **noise)
+    reads.append(reads[0][:37])      # ragged: a truncated read
+    out, ll, st = dec.decode(reads)
+    for i, r in enumerate(reads):
+        s, oll = orc.decode(r)
+        assert out[i] == s, i
+        assert ll[i] == oll or (math.isinf(oll) and ll[i] == oll), i
+        assert st[i] == (1 if s == "" and math.isinf(oll) else 0)
+    dec.close()
+
+
+def test_ragged_and_degenerate_reads(da, oracle_mod, ref_data):
+    """empty read, 1-nt read, unexplainable read (no valid path -> empty string, viterbi.cpp:198-201)."""
+    flags = dict(sub=0., dup=0., del_open=0., global_=True)
+    dec, orc = _pair(da, oracle_mod, ref_data, "l4c4.json", flags)
+    good = da.read_fastseqs(os.path.join(ref_data, "hello.fa"))[0][1]
+    reads = ["", "A", "ACGTACGTACGT", good, good.lower()]
+    out, ll, st = dec.decode(reads)
+    for i, r in enumerate(reads):
+        s, oll = orc.decode(r)
+        assert out[i] == s and ll[i] == oll
+    assert list(st) == [1, 1, 1, 0, 0]
+    dec.close()
+
+
+def test_local_mode_many_reads_order_preserved(da, oracle_mod, ref_data):
+    from synth import synthetic_reads
+    dec, orc = _pair(da, oracle_mod, ref_data, "mr2l4c4.json", dict())
+    rng = random.Random(5)
+    reads = []
+    for k in range(40):
+        reads.extend(synthetic_reads(orc.machine, 1, rng.randint(1, 6), seed=300 + k, sub=0.02, dele=0.005, dup=0.005))
+    out, ll, st = dec.decode(reads)
+    for i, r in enumerate(reads):
+        s, oll = orc.decode(r)
+        assert out[i] == s and ll[i] == oll, i
+    dec.close()
+
+
+def test_decode_fastseqs_drop_in(da, ref_data):
+    m = da.Machine.fromFile(os.path.join(ref_data, "s16h74l4c4.json"))
+    res = da.decode_fastseqs(os.path.join(ref_data, "hello.s16h74.del.fa"), m, da.MutatorParams.fromFlags())
+    want = open(os.path.join(ref_data, "hello.exact.bits")).read().strip()
+    assert res == [("data/hello.txt", want, 54.416887183956284)]
+
+
+def test_output_overflow_is_reported(da, ref_data):
+    dec = da.ViterbiDecoder(da.Machine.fromFile(os.path.join(ref_data, "l4c4.json")), da.MutatorParams.fromFlags())
+    good = da.read_fastseqs(os.path.join(ref_data, "hello.fa"))[0][1]
+    out, ll, st = dec.decode([good], out_cap=8)
+    assert st[0] == 2 and out[0] == ""
+    dec.close()
+
+
+def test_bad_base_rejected(da, ref_data):
+    dec = da.ViterbiDecoder(da.Machine.fromFile(os.path.join(ref_data, "l4c4.json")), da.MutatorParams.fromFlags())
+    with pytest.raises(ValueError):
+        dec.decode(["ACGTN"])
+    dec.close()
