@@ -132,6 +132,12 @@ class FlatModel:
                             + [v.len[i] for i in range(v.n_len)]),
             alphabet=v.alphabet.decode(), sym_logp=np.array(list(v.sym_logp)))
 
+    def precompile(self):
+        """JIT-specialise the tier-A fill kernel for this machine into dnastore_amd/kcache (no GPU needed)."""
+        buf = ctypes.create_string_buffer(1024)
+        _l.check(_l.lib().dnas_tiera_precompile(self.view, buf, 1024))
+        return buf.value.decode()
+
     def __del__(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             _l.lib().dnas_flat_free(self._h)
@@ -184,6 +190,11 @@ class ViterbiDecoder:
 
     def sync(self):
         _l.check(_l.lib().dnas_model_sync(self._h))
+
+    @property
+    def tier(self):
+        """'tier A: <shape>' or 'tier B: <reason>' -- which fill kernel serves this machine."""
+        return _l.lib().dnas_model_tier(self._h).decode()
 
     def stats(self):
         s = _l.BatchStatsC()

@@ -15,6 +15,7 @@ struct DevModel {
   // out-edges per source (dirty marking)
   const int32_t* eoutPtr; const int32_t* eoutDst;
   const int32_t* noutPtr; const int32_t* noutDst;
+  const int32_t* slotOf;  // tier A: state -> lattice slot (nullptr: identity)
   const uint8_t* mdl;   // [N]
   const uint8_t* ctx;   // [N*D]
   double noGap, delOpen, delExtend, delEnd, tanDup;

@@ -1,0 +1,95 @@
+#include "jit.hpp"
+
+#include <dlfcn.h>
+#include <hip/hiprtc.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+
+namespace dnas {
+namespace {
+
+uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
+  for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
+  return h;
+}
+
+std::string slurp(const std::string& path) {
+  std::ifstream in(path, std::ios::binary);
+  if (!in) throw std::runtime_error("cannot read " + path);
+  std::stringstream ss;
+  ss << in.rdbuf();
+  return ss.str();
+}
+
+}  // namespace
+
+std::string libraryDir() {
+  Dl_info info;
+  if (dladdr((void*)&libraryDir, &info) && info.dli_fname) {
+    std::string p = info.dli_fname;
+    const size_t s = p.rfind('/');
+    return s == std::string::npos ? "." : p.substr(0, s);
+  }
+  return ".";
+}
+
+std::vector<char> jitCompile(const std::string& sourcePath, const std::string& defines, const std::string& key) {
+  const std::string src = slurp(sourcePath);
+  char name[64];
+  snprintf(name, sizeof name, "%016llx", (unsigned long long)fnv1a(src, fnv1a(defines + "|" + key)));
+  const std::string cacheDir = libraryDir() + "/kcache";
+  const std::string cachePath = cacheDir + "/tiera_" + name + ".hsaco";
+  {
+    std::ifstream in(cachePath, std::ios::binary);
+    if (in) {
+      std::vector<char> code((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+      if (!code.empty()) return code;
+    }
+  }
+  std::vector<std::string> opts{"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17"};
+  {
+    std::stringstream ss(defines);
+    std::string line;
+    while (std::getline(ss, line))
+      if (!line.empty()) opts.push_back(line);
+  }
+  std::vector<const char*> copts;
+  for (const auto& o : opts) copts.push_back(o.c_str());
+  hiprtcProgram prog;
+  if (hiprtcCreateProgram(&prog, src.c_str(), "viterbi_tiera.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+    throw std::runtime_error("hiprtcCreateProgram failed");
+  const hiprtcResult rc = hiprtcCompileProgram(prog, (int)copts.size(), copts.data());
+  if (rc != HIPRTC_SUCCESS) {
+    size_t n = 0;
+    hiprtcGetProgramLogSize(prog, &n);
+    std::string log(n, '\0');
+    if (n) hiprtcGetProgramLog(prog, &log[0]);
+    hiprtcDestroyProgram(&prog);
+    throw std::runtime_error(std::string("hiprtc: ") + hiprtcGetErrorString(rc) + "\n" + log);
+  }
+  size_t n = 0;
+  hiprtcGetCodeSize(prog, &n);
+  std::vector<char> code(n);
+  hiprtcGetCode(prog, code.data());
+  hiprtcDestroyProgram(&prog);
+  // best-effort cache write (atomic rename; a read-only tree just skips it)
+  mkdir(cacheDir.c_str(), 0755);
+  const std::string tmp = cachePath + "." + std::to_string((long)getpid()) + ".tmp";
+  {
+    std::ofstream out(tmp, std::ios::binary);
+    if (out) {
+      out.write(code.data(), (std::streamsize)code.size());
+      out.close();
+      if (rename(tmp.c_str(), cachePath.c_str()) != 0) remove(tmp.c_str());
+    }
+  }
+  return code;
+}
+
+}  // namespace dnas

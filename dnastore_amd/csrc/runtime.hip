@@ -12,6 +12,8 @@
 #include "../../include/dnastore_amd.h"
 #include "device_model.h"
 #include "errors.hpp"
+#include "host/plan.hpp"
+#include "jit.hpp"
 
 extern "C" __global__ void viterbi_fill_kernel(DevModel, const uint8_t*, const uint64_t*, const int32_t*,
                                                const uint64_t*, double*, double*, unsigned long long*, int);
@@ -26,8 +28,37 @@ extern "C" __global__ void viterbi_traceback_kernel(DevModel, const uint8_t*, co
       return dnas::fail(DNAS_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));     \
   } while (0)
 
+// kernel-argument block of viterbi_fill_tiera (must mirror csrc/viterbi_tiera.hip)
+struct TierAArgs {
+  int N, local;
+  double noGap, delOpen, delExtend, delEnd, tanDup;
+  double sub[16];
+  double len[8];
+  double score[4];
+};
+struct TierALaunch {
+  TierAArgs a;
+  const unsigned* entTab;
+  const unsigned* metaTab;
+  const uint8_t* bases;
+  const uint64_t* readOff;
+  const int32_t* batchRead;
+  const uint64_t* slotOff;
+  double* arena;
+  double* outLoglike;
+  unsigned long long* roundsTotal;
+};
+
 struct dnas_model {
   int device = 0;
+  int tier = 0;                 // 1 = tier A (register/LDS-resident JIT kernel), 0 = tier B (global-memory kernel)
+  std::string tierNote;
+  dnas::TierAPlan plan;
+  hipModule_t module = nullptr;
+  hipFunction_t fillA = nullptr;
+  TierAArgs argsA{};
+  unsigned *dEntTab = nullptr, *dMetaTab = nullptr;
+  int32_t* dSlotOf = nullptr;
   hipStream_t stream = nullptr;
   DevModel dm{};
   std::vector<void*> owned;   // device allocations of the tables
@@ -114,8 +145,52 @@ extern "C" int dnas_model_create(const dnas_flat_model* fm, int device_id, size_
   d.tanDup = fm->tan_dup;
   memcpy(d.sub, fm->sub, sizeof d.sub);
   for (int k = 0; k < kMaxLen; ++k) d.len[k] = k < fm->n_len ? fm->len[k] : 0.;
+  d.slotOf = nullptr;
   if (hipMalloc((void**)&m->dRounds, sizeof(unsigned long long)) != hipSuccess)
     return bail(dnas::fail(DNAS_E_DEVICE, "hipMalloc failed"));
+  // ---- tier A: specialise the register/LDS-resident kernel for this machine
+  {
+    const char* force = getenv("DNAS_TIER");
+    if (force && (force[0] == 'B' || force[0] == 'b')) {
+      m->tierNote = "tier B forced by DNAS_TIER";
+    } else {
+      m->plan = dnas::buildTierAPlan(*fm);
+      if (!m->plan.ok) {
+        m->tierNote = "tier B: " + m->plan.whyNot;
+      } else {
+        try {
+          const std::vector<char> code =
+              dnas::jitCompile(dnas::libraryDir() + "/csrc/viterbi_tiera.hip", m->plan.defines, m->plan.key);
+          if (hipModuleLoadData(&m->module, code.data()) != hipSuccess ||
+              hipModuleGetFunction(&m->fillA, m->module, "viterbi_fill_tiera") != hipSuccess)
+            throw std::runtime_error("hipModuleLoadData/GetFunction failed");
+          const dnas::TierAPlan& p = m->plan;
+          if (hipMalloc((void**)&m->dEntTab, p.entTab.size() * 4) != hipSuccess ||
+              hipMalloc((void**)&m->dMetaTab, p.metaTab.size() * 4) != hipSuccess ||
+              hipMalloc((void**)&m->dSlotOf, p.slotOf.size() * 4) != hipSuccess ||
+              hipMemcpy(m->dEntTab, p.entTab.data(), p.entTab.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+              hipMemcpy(m->dMetaTab, p.metaTab.data(), p.metaTab.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+              hipMemcpy(m->dSlotOf, p.slotOf.data(), p.slotOf.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+            throw std::runtime_error("tier A table upload failed");
+          TierAArgs& a = m->argsA;
+          a.N = N; a.local = fm->local;
+          a.noGap = fm->no_gap; a.delOpen = fm->del_open; a.delExtend = fm->del_extend; a.delEnd = fm->del_end;
+          a.tanDup = fm->tan_dup;
+          memcpy(a.sub, fm->sub, sizeof a.sub);
+          for (int k = 0; k < 8; ++k) a.len[k] = k < fm->n_len ? fm->len[k] : 0.;
+          memcpy(a.score, p.score, sizeof a.score);
+          d.slotOf = m->dSlotOf;
+          d.Npad = p.NS;          // lattice row stride = slots
+          m->tier = 1;
+          m->tierNote = "tier A: " + p.key;
+        } catch (const std::exception& e) {
+          m->tier = 0;
+          m->tierNote = std::string("tier B: tier A unavailable: ") + e.what();
+          if (getenv("DNAS_TIER")) return bail(dnas::fail(DNAS_E_DEVICE, m->tierNote));   // DNAS_TIER=A: fail loudly
+        }
+      }
+    }
+  }
   size_t freeB = 0, totalB = 0;
   if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return bail(dnas::fail(DNAS_E_DEVICE, "hipMemGetInfo failed"));
   m->arenaCap = arena_bytes ? arena_bytes : (size_t)((double)freeB * 0.6);
@@ -131,6 +206,10 @@ extern "C" void dnas_model_destroy(dnas_model* m) {
   for (void* p : m->owned) (void)hipFree(p);
   if (m->arena) (void)hipFree(m->arena);
   if (m->dRounds) (void)hipFree(m->dRounds);
+  if (m->dEntTab) (void)hipFree(m->dEntTab);
+  if (m->dMetaTab) (void)hipFree(m->dMetaTab);
+  if (m->dSlotOf) (void)hipFree(m->dSlotOf);
+  if (m->module) (void)hipModuleUnload(m->module);
   if (m->dBatchRead) (void)hipFree(m->dBatchRead);
   if (m->dSlotOff) (void)hipFree(m->dSlotOff);
   if (m->dReadOff) (void)hipFree(m->dReadOff);
@@ -237,10 +316,19 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
     const int64_t s = batchStart[b];
     const int nB = (int)(batchStart[b + 1] - s);
     HIP_TRY(hipEventRecord(m->events[3 * b], m->stream));
-    hipLaunchKernelGGL(viterbi_fill_kernel, dim3(nB), dim3(kFillThreads), ldsBytes, m->stream, d, d_bases,
-                       (const uint64_t*)m->dReadOff, (const int32_t*)(m->dBatchRead + s),
-                       (const uint64_t*)(m->dSlotOff + s), m->arena, d_out_loglike, m->dRounds, maskWords);
-    HIP_TRY(hipGetLastError());
+    if (m->tier == 1) {
+      TierALaunch la{m->argsA, m->dEntTab, m->dMetaTab, d_bases, m->dReadOff, m->dBatchRead + s, m->dSlotOff + s,
+                     m->arena, d_out_loglike, m->dRounds};
+      size_t laSize = sizeof la;
+      void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &la, HIP_LAUNCH_PARAM_BUFFER_SIZE, &laSize, HIP_LAUNCH_PARAM_END};
+      HIP_TRY(hipModuleLaunchKernel(m->fillA, (unsigned)nB, 1, 1, (unsigned)m->plan.T, 1, 1, (unsigned)m->plan.ldsBytes,
+                                    m->stream, nullptr, config));
+    } else {
+      hipLaunchKernelGGL(viterbi_fill_kernel, dim3(nB), dim3(kFillThreads), ldsBytes, m->stream, d, d_bases,
+                         (const uint64_t*)m->dReadOff, (const int32_t*)(m->dBatchRead + s),
+                         (const uint64_t*)(m->dSlotOff + s), m->arena, d_out_loglike, m->dRounds, maskWords);
+      HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipEventRecord(m->events[3 * b + 1], m->stream));
     hipLaunchKernelGGL(viterbi_traceback_kernel, dim3((nB + kTraceThreads - 1) / kTraceThreads), dim3(kTraceThreads), 0,
                        m->stream, d, d_bases, (const uint64_t*)m->dReadOff, (const int32_t*)(m->dBatchRead + s),
@@ -319,8 +407,39 @@ extern "C" int dnas_model_read_lattice(dnas_model* m, int64_t slot, int64_t len,
     if (m->lastBatchRead[pos] == (int32_t)slot) break;
   if (pos == m->lastBatchRead.size()) return dnas::fail(DNAS_E_INVALID, "no such read in the last batch");
   const double* src = m->arena + m->lastSlotOff[pos];
+  if (m->tier == 1) {
+    // slot order -> state order
+    const size_t rows = (size_t)(len + 1) * lanes, NS = (size_t)d.Npad;
+    std::vector<double> tmp(rows * NS);
+    HIP_TRY(hipMemcpy(tmp.data(), src, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t r = 0; r < rows; ++r)
+      for (int j = 0; j < d.N; ++j) out[r * (size_t)d.N + j] = tmp[r * NS + (size_t)m->plan.slotOf[j]];
+    return DNAS_OK;
+  }
   // strip the row padding: [pos][lane][Npad] -> [pos][lane][N]
   HIP_TRY(hipMemcpy2D(out, (size_t)d.N * sizeof(double), src, (size_t)d.Npad * sizeof(double),
                       (size_t)d.N * sizeof(double), (size_t)(len + 1) * lanes, hipMemcpyDeviceToHost));
   return DNAS_OK;
 }
+
+// Build-time helper: specialise and compile the tier-A kernel for a machine without touching
+// a GPU (fills dnastore_amd/kcache so that the GPU box finds the code object ready).
+extern "C" int dnas_tiera_precompile(const dnas_flat_model* fm, char* note, size_t note_cap) {
+  if (!fm) return dnas::fail(DNAS_E_INVALID, "null argument");
+  try {
+    const dnas::TierAPlan p = dnas::buildTierAPlan(*fm);
+    std::string msg;
+    if (!p.ok) {
+      msg = "tier B: " + p.whyNot;
+    } else {
+      (void)dnas::jitCompile(dnas::libraryDir() + "/csrc/viterbi_tiera.hip", p.defines, p.key);
+      msg = "tier A: " + p.key + " lds=" + std::to_string(p.ldsBytes) + " fill=" + std::to_string(p.fillRatio);
+    }
+    if (note && note_cap) { strncpy(note, msg.c_str(), note_cap - 1); note[note_cap - 1] = 0; }
+    return DNAS_OK;
+  } catch (const std::exception& e) {
+    return dnas::fail(DNAS_E_DEVICE, e.what());
+  }
+}
+
+extern "C" const char* dnas_model_tier(const dnas_model* m) { return m ? m->tierNote.c_str() : ""; }

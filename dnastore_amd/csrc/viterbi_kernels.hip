@@ -198,11 +198,12 @@ viterbi_traceback_kernel(DevModel m, const uint8_t* __restrict__ bases, const ui
   const double* lat = arena + slotOff[b];
   const int N = m.N, D_ = m.D, lanes = m.D + 2;
   const size_t Npad = (size_t)m.Npad;
+  const int32_t* __restrict__ slotOf = m.slotOf;
   char* out = outSym + outOff[read];
   const long cap = (long)(outOff[read + 1] - outOff[read]);
   long n = 0;
 
-#define CELL(st, ps, ln) lat[((size_t)(ps) * lanes + (size_t)(ln)) * Npad + (size_t)(st)]
+#define CELL(st, ps, ln) lat[((size_t)(ps) * lanes + (size_t)(ln)) * Npad + (size_t)(slotOf ? slotOf[st] : (st))]
   if (!(CELL(N - 1, L, 0) > kNegInf)) {  // viterbi.cpp:198-201
     outLen[read] = 0;
     outStatus[read] = 1;  // DNAS_READ_NO_PATH

@@ -1,0 +1,312 @@
+// viterbi_tiera.hip -- the fast lattice-fill kernel ("tier A"), specialised at JIT time
+// for one machine (see host/plan.hpp).  Replaces the ViterbiMatrix constructor's fill loop
+// (reference src/viterbi.cpp:62-176) for machines whose state set fits one CU.
+//
+// One work-group (DNAS_T threads, one per CU) per read.  Thread t owns the states in
+// slots t, t+T, t+2T, ... ("rows" k = 0..K-1); their S and D cells of the current column
+// live in REGISTERS for the whole in-column fixpoint.  What other threads need is
+// published in LDS:
+//     X[slot]  = max(D+delExtend, S+delOpen)    every state  (what an emit edge reads, viterbi.cpp:124)
+//     DN[cell], SN[cell]                         states that are sources of null edges, or
+//                                                "heavy" destinations (in-degree > threshold)
+// The edge lists are compiled by the host into per-thread 32-bit entries that are loaded
+// into registers once per read; the row shape (entries per row) is a compile-time constant,
+// so every register index is static.  A column is: gather S of the previous column from
+// LDS -> sweep all rows until no cell grows (monotone max-plus: the least fixpoint is
+// schedule independent, so the cells equal the reference's worklist result bit for bit)
+// -> duplication lanes -> coalesced stores of the six lanes in slot order.
+//
+// fp64 throughout, reference operand order, no contraction / fast-math.
+//
+// Compile-time parameters (-D):  DNAS_T threads, DNAS_K rows, DNAS_D dup lanes,
+//   DNAS_NS slots (= K*T), DNAS_C LDS cells (incl. two dummies),
+//   DNAS_ROWS  brace list of {emit pulls, null pulls, pushes, publishes} per row.
+#ifndef __HIPCC_RTC__
+#include <hip/hip_runtime.h>   // hiprtc provides the device runtime implicitly
+#endif
+
+#ifndef DNAS_T
+#error "compile with -DDNAS_T= -DDNAS_K= -DDNAS_D= -DDNAS_NS= -DDNAS_C= -DDNAS_ROWS="
+#endif
+
+struct RowShape { int ee, en, ep, ec; };
+constexpr RowShape kRows[DNAS_K] = {DNAS_ROWS};
+
+constexpr int rowOffset(int k) {
+  int o = 0;
+  for (int i = 0; i < k; ++i) o += kRows[i].ee + kRows[i].en + kRows[i].ep + kRows[i].ec;
+  return o;
+}
+constexpr int kEntries = rowOffset(DNAS_K) > 0 ? rowOffset(DNAS_K) : 1;
+
+template <int V> struct IntC { static constexpr int value = V; };
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(IntC<I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// kernel-argument block (mirrors runtime.hip TierAArgs)
+struct TierAArgs {
+  int N;            // real states
+  int local;
+  double noGap, delOpen, delExtend, delEnd, tanDup;
+  double sub[16];
+  double len[8];
+  double score[4];  // score table, score[0] == 0
+};
+
+// LDS map (bytes):  X[NS] | DN[C] | SN[C] | negInf | score[4] | sub[16] | len[8] | red[T/64]
+constexpr int kXBytes = DNAS_NS * 8;
+constexpr int kCellBytes = DNAS_C * 8;           // SN[cell] sits kCellBytes behind DN[cell]
+constexpr int kTabBase = kXBytes + 2 * kCellBytes + 8;
+
+// entry bit fields (host/plan.cpp packs them):
+//   [0:19)  byte address in LDS of the source value: X[src slot] (emit pull), DN[src cell]
+//           (null pull) or DN[dest cell] (push, publish)
+//   [19:24) score index << 3   (byte offset into the LDS score table)
+//   [24:26) emitted base       (emit pull / emit push)
+//   [26]    flag: push = emit edge;  publish = heavy cell (also receives pushes)
+//   [27]    publish: state has a cell
+#define ENT_ADDR(e) ((e) & 0x7ffffu)
+#define ENT_SCOFF(e) (((e) >> 19) & 0x18u)
+#define ENT_BASE(e) (((e) >> 24) & 3u)
+#define ENT_FLAG(e) (((e) >> 26) & 1u)
+#define ENT_HASCELL(e) (((e) >> 27) & 1u)
+
+__device__ __forceinline__ double dmax(double a, double b) { return __builtin_fmax(a, b); }
+__device__ __forceinline__ double ldsRead(const char* base, unsigned byteOff) {
+  return *reinterpret_cast<const double*>(base + byteOff);
+}
+__device__ __forceinline__ void ldsWrite(char* base, unsigned byteOff, double v) {
+  *reinterpret_cast<double*>(base + byteOff) = v;
+}
+__device__ __forceinline__ void ldsMax(char* base, unsigned byteOff, double v) {
+  __hip_atomic_fetch_max(reinterpret_cast<double*>(base + byteOff), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// keep a register-resident entry opaque inside the sweep loop, so that nothing derived
+// from it is hoisted out and kept live across iterations
+__device__ __forceinline__ unsigned opaque(unsigned v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+constexpr double kNegInf = -__builtin_huge_val();
+
+extern "C" __global__ void __launch_bounds__(DNAS_T)
+viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntries][T]
+                   const unsigned* __restrict__ metaTab,                // [K][T]: mdl | ctx<<4 | flags
+                   const unsigned char* __restrict__ bases, const unsigned long long* __restrict__ readOff,
+                   const int* __restrict__ batchRead, const unsigned long long* __restrict__ slotOff,
+                   double* __restrict__ arena, double* __restrict__ outLoglike,
+                   unsigned long long* __restrict__ roundsTotal) {
+  extern __shared__ double lds[];
+  constexpr int T = DNAS_T, K = DNAS_K, D_ = DNAS_D, lanes = DNAS_D + 2, NS = DNAS_NS;
+  const int tid = threadIdx.x;
+  char* const ldsB = reinterpret_cast<char*>(lds);
+  double* const X = lds;
+  const double* const subL = lds + (kTabBase / 8) + 4;
+  const double* const lenL = subL + 16;
+
+  const int read = batchRead[blockIdx.x];
+  const unsigned char* seq = bases + readOff[read];
+  const int L = (int)(readOff[read + 1] - readOff[read]);
+  double* const lat = arena + slotOff[blockIdx.x];
+
+  unsigned E[kEntries];
+  static_for<0, kEntries>([&](auto m) { E[m.value] = entTab[(size_t)m.value * T + tid]; });
+#define META(k) (metaTab[(size_t)(k) * T + tid])
+
+  double S[K], Dv[K];
+  unsigned rounds = 0;
+
+  // LDS init: everything -inf (dummy cells / slots stay that way), then the small tables
+  for (int i = tid; i < NS + 2 * DNAS_C + 1; i += T) lds[i] = kNegInf;
+  if (tid < 4) lds[kTabBase / 8 + tid] = a.score[tid];
+  if (tid < 16) lds[kTabBase / 8 + 4 + tid] = a.sub[tid];
+  if (tid < 8) lds[kTabBase / 8 + 20 + tid] = a.len[tid];
+  __syncthreads();
+
+  for (int pos = 0; pos <= L; ++pos) {
+    double* const col = lat + (size_t)pos * lanes * NS;
+    const double* const prev = col - (size_t)lanes * NS;
+    const int x = pos > 0 ? seq[pos - 1] : 0;
+
+    // ---- phase A (viterbi.cpp:75-79,92-95,101-103): S of this column from the previous
+    // column's S (parked in X[] by the previous iteration) and the T1 lane.  Heavy
+    // destinations receive their emit-in candidates by ds_max pushes into SN[cell] (their
+    // owners reset the cell at the end of the previous column).
+    if (pos > 0) {
+      static_for<0, K>([&](auto kc) {
+        constexpr int k = kc.value, o = rowOffset(k);
+        static_for<0, kRows[k].ep>([&](auto ec) {
+          const unsigned en = E[o + kRows[k].ee + kRows[k].en + ec.value];
+          if (ENT_FLAG(en)) {
+            const double cand = ((S[k] + ldsRead(ldsB, kTabBase + ENT_SCOFF(en))) + a.noGap) + subL[ENT_BASE(en) * 4 + x];
+            if (cand > kNegInf) ldsMax(ldsB, ENT_ADDR(en) + kCellBytes, cand);
+          }
+        });
+      });
+    }
+    static_for<0, K>([&](auto kc) {
+      constexpr int k = kc.value, o = rowOffset(k);
+      const int slot = k * T + tid;
+      const unsigned meta = META(k);
+      double s;
+      if (pos == 0) {
+        s = (slot < a.N && (a.local || (meta & 0x80000000u))) ? 0.0 : kNegInf;   // bit31: reference state 0
+      } else {
+        s = kNegInf;
+        static_for<0, kRows[k].ee>([&](auto ec) {
+          const unsigned en = E[o + ec.value];
+          s = dmax(s, ((ldsRead(ldsB, ENT_ADDR(en)) + ldsRead(ldsB, kTabBase + ENT_SCOFF(en))) + a.noGap) +
+                          subL[ENT_BASE(en) * 4 + x]);
+        });
+        if ((meta & 15u) > 0 && slot < a.N) s = dmax(s, prev[(size_t)2 * NS + slot] + subL[((meta >> 4) & 3u) * 4 + x]);
+      }
+      S[k] = s;
+    });
+    __syncthreads();   // every gather of the previous column (and every phase-A push) is done
+
+    // ---- start of the fixpoint: D = -inf, X = max(D+delExtend, S+delOpen); cells published;
+    // every push edge fired once with the starting values
+    static_for<0, K>([&](auto kc) {
+      constexpr int k = kc.value, o = rowOffset(k);
+      double s = S[k];
+      static_for<0, kRows[k].ec>([&](auto ec) {
+        const unsigned en = E[o + kRows[k].ee + kRows[k].en + kRows[k].ep + ec.value];
+        if (ENT_HASCELL(en)) {
+          if (ENT_FLAG(en)) {        // heavy destination: fold in what phase A pushed, never lower the cell
+            s = dmax(s, ldsRead(ldsB, ENT_ADDR(en) + kCellBytes));
+            ldsMax(ldsB, ENT_ADDR(en) + kCellBytes, s);
+          } else {
+            ldsWrite(ldsB, ENT_ADDR(en) + kCellBytes, s);
+            ldsWrite(ldsB, ENT_ADDR(en), kNegInf);
+          }
+        }
+      });
+      S[k] = s;
+      Dv[k] = kNegInf;
+      const double xv = dmax(kNegInf + a.delExtend, s + a.delOpen);
+      X[k * T + tid] = xv;
+      static_for<0, kRows[k].ep>([&](auto ec) {
+        const unsigned en = E[o + kRows[k].ee + kRows[k].en + ec.value];
+        const double sc = ldsRead(ldsB, kTabBase + ENT_SCOFF(en));
+        if (ENT_FLAG(en)) {
+          if (xv + sc > kNegInf) ldsMax(ldsB, ENT_ADDR(en), xv + sc);
+        } else {
+          if (s + sc > kNegInf) ldsMax(ldsB, ENT_ADDR(en) + kCellBytes, s + sc);
+        }
+      });
+    });
+    __syncthreads();
+
+    // ---- phase B: sweeps to the fixpoint (viterbi.cpp:97-99,110-159)
+    for (;;) {
+      int changed = 0;
+      static_for<0, K>([&](auto kc) {
+        constexpr int k = kc.value, o = rowOffset(k);
+        double s = S[k], d = Dv[k];
+        static_for<0, kRows[k].ee>([&](auto ec) {
+          const unsigned en = opaque(E[o + ec.value]);
+          d = dmax(d, ldsRead(ldsB, ENT_ADDR(en)) + ldsRead(ldsB, kTabBase + ENT_SCOFF(en)));
+        });
+        static_for<0, kRows[k].en>([&](auto ec) {
+          const unsigned en = opaque(E[o + kRows[k].ee + ec.value]);
+          const double sc = ldsRead(ldsB, kTabBase + ENT_SCOFF(en));
+          d = dmax(d, ldsRead(ldsB, ENT_ADDR(en)) + sc);
+          s = dmax(s, ldsRead(ldsB, ENT_ADDR(en) + kCellBytes) + sc);
+        });
+        s = dmax(s, d + a.delEnd);
+        if (s != S[k] || d != Dv[k]) {
+          changed = 1;
+          S[k] = s;
+          Dv[k] = d;
+          const double xv = dmax(d + a.delExtend, s + a.delOpen);
+          X[k * T + tid] = xv;
+          static_for<0, kRows[k].ec>([&](auto ec) {
+            const unsigned en = opaque(E[o + kRows[k].ee + kRows[k].en + kRows[k].ep + ec.value]);
+            if (ENT_HASCELL(en)) {   // a heavy destination's cell also receives pushes: only ever raise it
+              ldsMax(ldsB, ENT_ADDR(en) + kCellBytes, s);
+              ldsMax(ldsB, ENT_ADDR(en), d);
+            }
+          });
+          static_for<0, kRows[k].ep>([&](auto ec) {
+            const unsigned en = opaque(E[o + kRows[k].ee + kRows[k].en + ec.value]);
+            const double sc = ldsRead(ldsB, kTabBase + ENT_SCOFF(en));
+            if (ENT_FLAG(en)) {
+              ldsMax(ldsB, ENT_ADDR(en), xv + sc);
+            } else {
+              ldsMax(ldsB, ENT_ADDR(en), d + sc);
+              ldsMax(ldsB, ENT_ADDR(en) + kCellBytes, s + sc);
+            }
+          });
+        }
+      });
+      ++rounds;
+      if (!__syncthreads_or(changed)) break;
+    }
+
+    // ---- phase C: duplication lanes (viterbi.cpp:105-106,161-168), lattice stores in slot
+    // order (coalesced), S parked in X[] for the next column's gathers, heavy cells reset
+    static_for<0, K>([&](auto kc) {
+      constexpr int k = kc.value, o = rowOffset(k);
+      const int slot = k * T + tid;
+      const double s = S[k];
+      X[slot] = s;
+      static_for<0, kRows[k].ec>([&](auto ec) {
+        const unsigned en = E[o + kRows[k].ee + kRows[k].en + kRows[k].ep + ec.value];
+        if (ENT_HASCELL(en) && ENT_FLAG(en)) {
+          ldsWrite(ldsB, ENT_ADDR(en) + kCellBytes, kNegInf);
+          ldsWrite(ldsB, ENT_ADDR(en), kNegInf);
+        }
+      });
+      if (slot < a.N) {
+        const unsigned meta = META(k);
+        const unsigned mdl = meta & 15u;
+        col[slot] = s;
+        col[(size_t)NS + slot] = Dv[k];
+        static_for<0, D_>([&](auto qc) {
+          constexpr int q = qc.value;
+          double t = kNegInf;
+          if (pos > 0 && (unsigned)q < mdl) {
+            if ((unsigned)q + 1 < mdl)
+              t = prev[(size_t)(3 + q) * NS + slot] + subL[((meta >> (4 + 2 * (q + 1))) & 3u) * 4 + x];
+            t = dmax(t, (s + a.tanDup) + lenL[q]);
+          }
+          col[(size_t)(2 + q) * NS + slot] = t;
+        });
+      }
+    });
+    __syncthreads();   // X[] now holds S(pos) for everyone
+  }
+
+  // ---- loglike (viterbi.h:102); local mode overwrites the end state with the column max
+  // (viterbi.cpp:171-173).  bit30 of meta marks the reference's last state.
+  double* const red = lds + (kTabBase / 8) + 28;
+  double* const lastS = lat + (size_t)L * lanes * NS;
+  double best = kNegInf;
+  static_for<0, K>([&](auto kc) {
+    constexpr int k = kc.value;
+    const bool isEnd = (META(k) & 0x40000000u) != 0;
+    if (a.local ? (k * T + tid < a.N) : isEnd) best = dmax(best, S[k]);
+  });
+  for (int off = 32; off > 0; off >>= 1) best = dmax(best, __shfl_down(best, off, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = best;
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < T / 64; ++w) best = dmax(best, red[w]);
+    red[0] = best;
+    outLoglike[read] = best;
+    atomicAdd(roundsTotal, (unsigned long long)rounds);
+  }
+  __syncthreads();
+  if (a.local) {
+    static_for<0, K>([&](auto kc) {
+      constexpr int k = kc.value;
+      if (META(k) & 0x40000000u) lastS[k * T + tid] = red[0];
+    });
+  }
+}

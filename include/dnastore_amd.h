@@ -142,6 +142,12 @@ int dnas_viterbi_batch_device(dnas_model *model, int64_t n_reads, const uint64_t
                               uint32_t *d_out_len, double *d_out_loglike, uint8_t *d_out_status);
 int dnas_model_sync(dnas_model *model);
 
+/* Which fill kernel serves this model: "tier A: <shape>" (register/LDS-resident kernel, JIT-specialised
+ * for the machine) or "tier B: <reason>" (general global-memory kernel).  DNAS_TIER=B forces tier B. */
+const char *dnas_model_tier(const dnas_model *model);
+/* Specialise + compile the tier-A kernel for a machine ahead of time (no GPU needed). */
+int dnas_tiera_precompile(const dnas_flat_model *fm, char *note, size_t note_cap);
+
 /* Device-time accounting of the last batch call (HIP events on the model's stream). */
 typedef struct dnas_batch_stats {
   double fill_ms, traceback_ms;   /* summed kernel durations          */
