@@ -1,8 +1,8 @@
 #include "plan.hpp"
 
 #include <algorithm>
+#include <array>
 #include <cstring>
-#include <functional>
 #include <numeric>
 #include <sstream>
 
@@ -26,7 +26,7 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
   if (K > kTierAMaxRows) return no("more than " + std::to_string(kTierAMaxRows * T) + " states");
   p.K = K; p.NS = K * T;
 
-  // score table: 0 plus up to three distinct input-symbol log-probabilities
+  // score classes: 0.0 plus up to three distinct input-symbol log-probabilities
   std::vector<double> scores{0.0};
   auto scoreIdx = [&](double s) -> int {
     for (size_t i = 0; i < scores.size(); ++i)
@@ -69,90 +69,106 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
       for (const Pull& q : emitIn[j]) pushes[q.src].push_back({cellOf[j], q.sc, q.base, 1});
       for (const Pull& q : nullIn[j]) pushes[q.src].push_back({cellOf[j], q.sc, 0, 0});
     }
-  auto nEE = [&](int j) { return heavy[j] ? 0 : (int)emitIn[j].size(); };
-  auto nEN = [&](int j) { return heavy[j] ? 1 : (int)nullIn[j].size(); };   // heavy: pull its own cell
-  auto nEP = [&](int j) { return (int)pushes[j].size(); };
-  auto nEC = [&](int j) { return hasCell[j] ? 1 : 0; };
 
-  // chain depth: states with a single in-edge sit behind their predecessor, so that within a
-  // sweep (rows run in order) a value travels down a whole chain
-  std::vector<int> depth(N, 0);
-  for (int it = 0; it < 64; ++it) {
-    bool any = false;
-    for (int j = 0; j < N; ++j) {
-      if (emitIn[j].size() + nullIn[j].size() != 1) continue;
-      const int src = emitIn[j].empty() ? nullIn[j][0].src : emitIn[j][0].src;
-      const int d = std::min(depth[src] + 1, 63);
-      if (d > depth[j] && src != j) { depth[j] = d; any = true; }
+  // per-state entry counts: emit/null pulls by score class, pushes, publish
+  typedef std::array<int, 10> Counts;   // e0..e3, n0..n3, ep, ec
+  std::vector<Counts> cnt(N);
+  for (int j = 0; j < N; ++j) {
+    Counts c{};
+    if (heavy[j]) {
+      c[4] = 1;                           // heavy: one class-0 null pull of its own cell
+    } else {
+      for (const Pull& q : emitIn[j]) c[q.sc]++;
+      for (const Pull& q : nullIn[j]) c[4 + q.sc]++;
     }
-    if (!any) break;
+    c[8] = (int)pushes[j].size();
+    c[9] = hasCell[j] ? 1 : 0;
+    cnt[j] = c;
   }
-
+  // Rows come out (nearly) homogeneous when identical count vectors sit together; ordering the
+  // classes by (scored emit pulls, scored null pulls, plain null pulls, plain emit pulls, ...)
+  // gave the least padding on the reference's composites.  Ties keep reference state order.
+  auto sortKey = [&](const Counts& c) {
+    return std::array<int, 10>{c[1], c[2], c[3], c[5], c[6], c[7], c[4], c[0], c[8], c[9]};
+  };
   std::vector<int> order(N);
   std::iota(order.begin(), order.end(), 0);
-  auto cost = [&](int j) { return nEE(j) + 2 * nEN(j) + 3 * nEP(j) + nEC(j); };
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-    const int ca = cost(a), cb = cost(b);
-    if (ca != cb) return ca > cb;
-    if (nEN(a) != nEN(b)) return nEN(a) > nEN(b);
-    if (nEP(a) != nEP(b)) return nEP(a) > nEP(b);
-    if (nEC(a) != nEC(b)) return nEC(a) > nEC(b);
-    return depth[a] < depth[b];
-  });
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sortKey(cnt[a]) > sortKey(cnt[b]); });
   p.slotOf.assign(N, -1);
   p.stateOf.assign(p.NS, -1);
   for (int i = 0; i < N; ++i) { p.slotOf[order[i]] = i; p.stateOf[i] = order[i]; }
 
-  p.rows.assign(K, RowShape{0, 0, 0, 0});
+  p.rows.assign(K, RowShape{{0, 0, 0, 0}, {0, 0, 0, 0}, 0, 0});
   long real = 0;
   for (int i = 0; i < N; ++i) {
-    const int j = order[i];
+    const Counts& c = cnt[order[i]];
     RowShape& r = p.rows[i / T];
-    r.ee = std::max(r.ee, nEE(j)); r.en = std::max(r.en, nEN(j));
-    r.ep = std::max(r.ep, nEP(j)); r.ec = std::max(r.ec, nEC(j));
-    real += nEE(j) + nEN(j) + nEP(j) + nEC(j);
+    for (int s = 0; s < 4; ++s) { r.e[s] = std::max(r.e[s], c[s]); r.n[s] = std::max(r.n[s], c[4 + s]); }
+    r.ep = std::max(r.ep, c[8]); r.ec = std::max(r.ec, c[9]);
+    for (int q = 0; q < 10; ++q) real += c[q];
   }
+  auto rowEntries = [](const RowShape& r) { return r.e[0] + r.e[1] + r.e[2] + r.e[3] + r.n[0] + r.n[1] + r.n[2] + r.n[3] + r.ep + r.ec; };
   int nEnt = 0;
-  for (const RowShape& r : p.rows) nEnt += r.ee + r.en + r.ep + r.ec;
+  for (const RowShape& r : p.rows) {
+    nEnt += rowEntries(r);
+    if (r.e[0] + r.e[1] + r.e[2] + r.e[3] > 16) return no("more than 16 emit pulls in one row");
+  }
   p.nEntries = std::max(nEnt, 1);
-  if (nEnt > 48) return no("row shape needs more than 48 entry registers per thread");
+  if (nEnt > 56) return no("row shape needs more than 56 entry registers per thread");
   p.fillRatio = nEnt ? (double)real / ((double)nEnt * T) : 1.0;
 
-  // entries
-  // [0:19) LDS byte address | [19:24) score index << 3 | [24:26) base | [26] flag | [27] has cell
+  // entries.  Pulls are bare LDS byte addresses (no decode in the sweep); pushes and
+  // publishes carry flags:  [0:19) address of DN[cell] | [22:24) score class | [24:26) base |
+  // [26] push: emit edge / publish: heavy cell | [27] publish: has a cell
   const unsigned dnBase = (unsigned)p.NS;   // DN[] starts right behind X[] (in doubles)
-  auto ent = [](unsigned dblIdx, unsigned sc, unsigned base, unsigned flag, unsigned hasCell) {
-    return ((dblIdx * 8u) & 0x7ffffu) | ((sc & 3u) << 22) | ((base & 3u) << 24) | ((flag & 1u) << 26) | ((hasCell & 1u) << 27);
+  auto packed = [](unsigned dblIdx, unsigned sc, unsigned base, unsigned flag, unsigned hasCellBit) {
+    return ((dblIdx * 8u) & 0x7ffffu) | ((sc & 3u) << 22) | ((base & 3u) << 24) | ((flag & 1u) << 26) | ((hasCellBit & 1u) << 27);
   };
   p.entTab.assign((size_t)p.nEntries * T, 0);
   p.metaTab.assign((size_t)K * T, 0);
+  p.baseTab.assign((size_t)K * T, 0);
   int off = 0;
   for (int k = 0; k < K; ++k) {
     const RowShape& r = p.rows[k];
     for (int t = 0; t < T; ++t) {
       const int j = p.stateOf[(size_t)k * T + t];
       int m = off;
-      for (int e = 0; e < r.ee; ++e, ++m) {
-        unsigned v = ent((unsigned)p.xDummy, 0, 0, 0, 0);
-        if (j >= 0 && e < nEE(j)) v = ent((unsigned)p.slotOf[emitIn[j][e].src], emitIn[j][e].sc, emitIn[j][e].base, 0, 0);
-        p.entTab[(size_t)m * T + t] = v;
+      unsigned bases = 0;
+      int epos = 0;
+      for (int s = 0; s < 4; ++s) {
+        std::vector<const Pull*> mine;            // this state's emit pulls of class s, reference edge order
+        if (j >= 0 && !heavy[j])
+          for (const Pull& q : emitIn[j]) if (q.sc == s) mine.push_back(&q);
+        for (int e = 0; e < r.e[s]; ++e, ++m, ++epos) {
+          unsigned v = (unsigned)p.xDummy * 8u;
+          if (e < (int)mine.size()) {
+            v = (unsigned)p.slotOf[mine[e]->src] * 8u;
+            bases |= (unsigned)(mine[e]->base & 3) << (2 * epos);
+          }
+          p.entTab[(size_t)m * T + t] = v;
+        }
       }
-      for (int e = 0; e < r.en; ++e, ++m) {
-        unsigned v = ent(dnBase + (unsigned)readDummy, 0, 0, 0, 0);
-        if (j >= 0 && e < nEN(j))
-          v = heavy[j] ? ent(dnBase + (unsigned)cellOf[j], 0, 0, 0, 0)
-                       : ent(dnBase + (unsigned)cellOf[nullIn[j][e].src], nullIn[j][e].sc, 0, 0, 0);
-        p.entTab[(size_t)m * T + t] = v;
+      for (int s = 0; s < 4; ++s) {
+        std::vector<unsigned> mine;               // cells this state null-pulls with class s
+        if (j >= 0) {
+          if (heavy[j]) { if (s == 0) mine.push_back((unsigned)cellOf[j]); }
+          else for (const Pull& q : nullIn[j]) if (q.sc == s) mine.push_back((unsigned)cellOf[q.src]);
+        }
+        for (int e = 0; e < r.n[s]; ++e, ++m) {
+          unsigned v = (dnBase + (unsigned)readDummy) * 8u;
+          if (e < (int)mine.size()) v = (dnBase + mine[e]) * 8u;
+          p.entTab[(size_t)m * T + t] = v;
+        }
       }
       for (int e = 0; e < r.ep; ++e, ++m) {
-        unsigned v = ent(dnBase + (unsigned)writeDummy, 0, 0, 0, 0);
-        if (j >= 0 && e < nEP(j))
-          v = ent(dnBase + (unsigned)pushes[j][e].dstCell, pushes[j][e].sc, pushes[j][e].base, pushes[j][e].emit, 0);
+        unsigned v = packed(dnBase + (unsigned)writeDummy, 0, 0, 0, 0);
+        if (j >= 0 && e < (int)pushes[j].size())
+          v = packed(dnBase + (unsigned)pushes[j][e].dstCell, pushes[j][e].sc, pushes[j][e].base, pushes[j][e].emit, 0);
         p.entTab[(size_t)m * T + t] = v;
       }
       for (int e = 0; e < r.ec; ++e, ++m) {
-        unsigned v = ent(dnBase + (unsigned)readDummy, 0, 0, 0, 0);
-        if (j >= 0 && hasCell[j]) v = ent(dnBase + (unsigned)cellOf[j], 0, 0, heavy[j] ? 1 : 0, 1);
+        unsigned v = packed(dnBase + (unsigned)readDummy, 0, 0, 0, 0);
+        if (j >= 0 && hasCell[j]) v = packed(dnBase + (unsigned)cellOf[j], 0, 0, heavy[j] ? 1 : 0, 1);
         p.entTab[(size_t)m * T + t] = v;
       }
       unsigned meta = 0;
@@ -163,14 +179,17 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
         if (j == N - 1) meta |= 0x40000000u;
       }
       p.metaTab[(size_t)k * T + t] = meta;
+      p.baseTab[(size_t)k * T + t] = bases;
     }
-    off += r.ee + r.en + r.ep + r.ec;
+    off += rowEntries(r);
   }
 
   std::ostringstream rows, defs;
   for (int k = 0; k < K; ++k) {
+    const RowShape& r = p.rows[k];
     if (k) rows << ",";
-    rows << "{" << p.rows[k].ee << "," << p.rows[k].en << "," << p.rows[k].ep << "," << p.rows[k].ec << "}";
+    rows << "{{" << r.e[0] << "," << r.e[1] << "," << r.e[2] << "," << r.e[3] << "},{" << r.n[0] << "," << r.n[1] << ","
+         << r.n[2] << "," << r.n[3] << "}," << r.ep << "," << r.ec << "}";
   }
   defs << "-DDNAS_T=" << T << "\n-DDNAS_K=" << K << "\n-DDNAS_D=" << D << "\n-DDNAS_NS=" << p.NS << "\n-DDNAS_C=" << C
        << "\n-DDNAS_ROWS=" << rows.str();

@@ -19,7 +19,8 @@
 
 namespace dnas {
 
-struct RowShape { int ee, en, ep, ec; };
+// per row: emit pulls / null pulls by score class (class 0 = score 0.0), pushes, publishes
+struct RowShape { int e[4], n[4], ep, ec; };
 
 struct TierAPlan {
   bool ok = false;
@@ -31,7 +32,8 @@ struct TierAPlan {
   std::vector<int32_t> slotOf;    // [N]  state -> slot
   std::vector<int32_t> stateOf;   // [NS] slot -> state or -1
   std::vector<uint32_t> entTab;   // [nEntries][T]
-  std::vector<uint32_t> metaTab;  // [K][T]
+  std::vector<uint32_t> metaTab;  // [K][T]  mdl | ctx<<4 | flags
+  std::vector<uint32_t> baseTab;  // [K][T]  emitted base of each emit pull of the row, 2 bits each
   double score[4] = {0, 0, 0, 0};
   size_t ldsBytes = 0;
   double fillRatio = 0;           // real entries / padded entries

@@ -40,6 +40,7 @@ struct TierALaunch {
   TierAArgs a;
   const unsigned* entTab;
   const unsigned* metaTab;
+  const unsigned* baseTab;
   const uint8_t* bases;
   const uint64_t* readOff;
   const int32_t* batchRead;
@@ -57,7 +58,7 @@ struct dnas_model {
   hipModule_t module = nullptr;
   hipFunction_t fillA = nullptr;
   TierAArgs argsA{};
-  unsigned *dEntTab = nullptr, *dMetaTab = nullptr;
+  unsigned *dEntTab = nullptr, *dMetaTab = nullptr, *dBaseTab = nullptr;
   int32_t* dSlotOf = nullptr;
   hipStream_t stream = nullptr;
   DevModel dm{};
@@ -168,6 +169,8 @@ extern "C" int dnas_model_create(const dnas_flat_model* fm, int device_id, size_
           if (hipMalloc((void**)&m->dEntTab, p.entTab.size() * 4) != hipSuccess ||
               hipMalloc((void**)&m->dMetaTab, p.metaTab.size() * 4) != hipSuccess ||
               hipMalloc((void**)&m->dSlotOf, p.slotOf.size() * 4) != hipSuccess ||
+              hipMalloc((void**)&m->dBaseTab, p.baseTab.size() * 4) != hipSuccess ||
+              hipMemcpy(m->dBaseTab, p.baseTab.data(), p.baseTab.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
               hipMemcpy(m->dEntTab, p.entTab.data(), p.entTab.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
               hipMemcpy(m->dMetaTab, p.metaTab.data(), p.metaTab.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
               hipMemcpy(m->dSlotOf, p.slotOf.data(), p.slotOf.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
@@ -208,6 +211,7 @@ extern "C" void dnas_model_destroy(dnas_model* m) {
   if (m->dRounds) (void)hipFree(m->dRounds);
   if (m->dEntTab) (void)hipFree(m->dEntTab);
   if (m->dMetaTab) (void)hipFree(m->dMetaTab);
+  if (m->dBaseTab) (void)hipFree(m->dBaseTab);
   if (m->dSlotOf) (void)hipFree(m->dSlotOf);
   if (m->module) (void)hipModuleUnload(m->module);
   if (m->dBatchRead) (void)hipFree(m->dBatchRead);
@@ -317,7 +321,7 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
     const int nB = (int)(batchStart[b + 1] - s);
     HIP_TRY(hipEventRecord(m->events[3 * b], m->stream));
     if (m->tier == 1) {
-      TierALaunch la{m->argsA, m->dEntTab, m->dMetaTab, d_bases, m->dReadOff, m->dBatchRead + s, m->dSlotOff + s,
+      TierALaunch la{m->argsA, m->dEntTab, m->dMetaTab, m->dBaseTab, d_bases, m->dReadOff, m->dBatchRead + s, m->dSlotOff + s,
                      m->arena, d_out_loglike, m->dRounds};
       size_t laSize = sizeof la;
       void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &la, HIP_LAUNCH_PARAM_BUFFER_SIZE, &laSize, HIP_LAUNCH_PARAM_END};

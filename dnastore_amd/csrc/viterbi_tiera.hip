@@ -29,13 +29,27 @@
 #error "compile with -DDNAS_T= -DDNAS_K= -DDNAS_D= -DDNAS_NS= -DDNAS_C= -DDNAS_ROWS="
 #endif
 
-struct RowShape { int ee, en, ep, ec; };
+// per row: emit pulls / null pulls by score class (class 0 adds 0.0, i.e. nothing), pushes, publishes
+struct RowShape { int e[4], n[4], ep, ec; };
 constexpr RowShape kRows[DNAS_K] = {DNAS_ROWS};
 
+constexpr int rowEE(int k) { return kRows[k].e[0] + kRows[k].e[1] + kRows[k].e[2] + kRows[k].e[3]; }
+constexpr int rowEN(int k) { return kRows[k].n[0] + kRows[k].n[1] + kRows[k].n[2] + kRows[k].n[3]; }
 constexpr int rowOffset(int k) {
   int o = 0;
-  for (int i = 0; i < k; ++i) o += kRows[i].ee + kRows[i].en + kRows[i].ep + kRows[i].ec;
+  for (int i = 0; i < k; ++i) o += rowEE(i) + rowEN(i) + kRows[i].ep + kRows[i].ec;
   return o;
+}
+// score class of the e-th emit (null) pull of row k
+constexpr int emitClass(int k, int e) {
+  int c = 0;
+  while (e >= kRows[k].e[c]) { e -= kRows[k].e[c]; ++c; }
+  return c;
+}
+constexpr int nullClass(int k, int e) {
+  int c = 0;
+  while (e >= kRows[k].n[c]) { e -= kRows[k].n[c]; ++c; }
+  return c;
 }
 constexpr int kEntries = rowOffset(DNAS_K) > 0 ? rowOffset(DNAS_K) : 1;
 
@@ -63,11 +77,12 @@ constexpr int kXBytes = DNAS_NS * 8;
 constexpr int kCellBytes = DNAS_C * 8;           // SN[cell] sits kCellBytes behind DN[cell]
 constexpr int kTabBase = kXBytes + 2 * kCellBytes + 8;
 
-// entry bit fields (host/plan.cpp packs them):
-//   [0:19)  byte address in LDS of the source value: X[src slot] (emit pull), DN[src cell]
-//           (null pull) or DN[dest cell] (push, publish)
+// entries (host/plan.cpp packs them).  Pull entries are bare LDS byte addresses -- X[src slot]
+// for an emit pull, DN[src cell] for a null pull -- and their score class is a compile-time
+// property of the entry's position in the row.  Push / publish entries carry flags:
+//   [0:19)  byte address of DN[cell]
 //   [19:24) score index << 3   (byte offset into the LDS score table)
-//   [24:26) emitted base       (emit pull / emit push)
+//   [24:26) emitted base       (emit push)
 //   [26]    flag: push = emit edge;  publish = heavy cell (also receives pushes)
 //   [27]    publish: state has a cell
 #define ENT_ADDR(e) ((e) & 0x7ffffu)
@@ -76,7 +91,13 @@ constexpr int kTabBase = kXBytes + 2 * kCellBytes + 8;
 #define ENT_FLAG(e) (((e) >> 26) & 1u)
 #define ENT_HASCELL(e) (((e) >> 27) & 1u)
 
-__device__ __forceinline__ double dmax(double a, double b) { return __builtin_fmax(a, b); }
+// v_max_f64 directly: no NaN can occur here (only -inf + finite / -inf + -inf), so the
+// canonicalising copies the compiler would add around fmax() are pure overhead
+__device__ __forceinline__ double dmax(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ double ldsRead(const char* base, unsigned byteOff) {
   return *reinterpret_cast<const double*>(base + byteOff);
 }
@@ -98,6 +119,7 @@ constexpr double kNegInf = -__builtin_huge_val();
 extern "C" __global__ void __launch_bounds__(DNAS_T)
 viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntries][T]
                    const unsigned* __restrict__ metaTab,                // [K][T]: mdl | ctx<<4 | flags
+                   const unsigned* __restrict__ baseTab,                // [K][T]: base of each emit pull, 2 bits each
                    const unsigned char* __restrict__ bases, const unsigned long long* __restrict__ readOff,
                    const int* __restrict__ batchRead, const unsigned long long* __restrict__ slotOff,
                    double* __restrict__ arena, double* __restrict__ outLoglike,
@@ -118,6 +140,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
   unsigned E[kEntries];
   static_for<0, kEntries>([&](auto m) { E[m.value] = entTab[(size_t)m.value * T + tid]; });
 #define META(k) (metaTab[(size_t)(k) * T + tid])
+  const double scoreC[4] = {0.0, a.score[1], a.score[2], a.score[3]};
 
   double S[K], Dv[K];
   unsigned rounds = 0;
@@ -142,7 +165,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
       static_for<0, K>([&](auto kc) {
         constexpr int k = kc.value, o = rowOffset(k);
         static_for<0, kRows[k].ep>([&](auto ec) {
-          const unsigned en = E[o + kRows[k].ee + kRows[k].en + ec.value];
+          const unsigned en = E[o + rowEE(k) + rowEN(k) + ec.value];
           if (ENT_FLAG(en)) {
             const double cand = ((S[k] + ldsRead(ldsB, kTabBase + ENT_SCOFF(en))) + a.noGap) + subL[ENT_BASE(en) * 4 + x];
             if (cand > kNegInf) ldsMax(ldsB, ENT_ADDR(en) + kCellBytes, cand);
@@ -159,10 +182,13 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
         s = (slot < a.N && (a.local || (meta & 0x80000000u))) ? 0.0 : kNegInf;   // bit31: reference state 0
       } else {
         s = kNegInf;
-        static_for<0, kRows[k].ee>([&](auto ec) {
-          const unsigned en = E[o + ec.value];
-          s = dmax(s, ((ldsRead(ldsB, ENT_ADDR(en)) + ldsRead(ldsB, kTabBase + ENT_SCOFF(en))) + a.noGap) +
-                          subL[ENT_BASE(en) * 4 + x]);
+        const unsigned bases = rowEE(k) > 0 ? baseTab[(size_t)k * T + tid] : 0u;
+        static_for<0, rowEE(k)>([&](auto ec) {
+          constexpr int cls = emitClass(k, ec.value);
+          // (S(src) + score) + noGap + sub: "+ 0.0" of class 0 is the identity on every value that occurs
+          double v = ldsRead(ldsB, E[o + ec.value]);
+          if constexpr (cls != 0) v = v + scoreC[cls];
+          s = dmax(s, (v + a.noGap) + subL[((bases >> (2 * ec.value)) & 3u) * 4 + x]);
         });
         if ((meta & 15u) > 0 && slot < a.N) s = dmax(s, prev[(size_t)2 * NS + slot] + subL[((meta >> 4) & 3u) * 4 + x]);
       }
@@ -176,7 +202,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
       constexpr int k = kc.value, o = rowOffset(k);
       double s = S[k];
       static_for<0, kRows[k].ec>([&](auto ec) {
-        const unsigned en = E[o + kRows[k].ee + kRows[k].en + kRows[k].ep + ec.value];
+        const unsigned en = E[o + rowEE(k) + rowEN(k) + kRows[k].ep + ec.value];
         if (ENT_HASCELL(en)) {
           if (ENT_FLAG(en)) {        // heavy destination: fold in what phase A pushed, never lower the cell
             s = dmax(s, ldsRead(ldsB, ENT_ADDR(en) + kCellBytes));
@@ -192,7 +218,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
       const double xv = dmax(kNegInf + a.delExtend, s + a.delOpen);
       X[k * T + tid] = xv;
       static_for<0, kRows[k].ep>([&](auto ec) {
-        const unsigned en = E[o + kRows[k].ee + kRows[k].en + ec.value];
+        const unsigned en = E[o + rowEE(k) + rowEN(k) + ec.value];
         const double sc = ldsRead(ldsB, kTabBase + ENT_SCOFF(en));
         if (ENT_FLAG(en)) {
           if (xv + sc > kNegInf) ldsMax(ldsB, ENT_ADDR(en), xv + sc);
@@ -209,15 +235,19 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
       static_for<0, K>([&](auto kc) {
         constexpr int k = kc.value, o = rowOffset(k);
         double s = S[k], d = Dv[k];
-        static_for<0, kRows[k].ee>([&](auto ec) {
-          const unsigned en = opaque(E[o + ec.value]);
-          d = dmax(d, ldsRead(ldsB, ENT_ADDR(en)) + ldsRead(ldsB, kTabBase + ENT_SCOFF(en)));
+        static_for<0, rowEE(k)>([&](auto ec) {
+          constexpr int cls = emitClass(k, ec.value);
+          double v = ldsRead(ldsB, E[o + ec.value]);
+          if constexpr (cls != 0) v = v + scoreC[cls];
+          d = dmax(d, v);
         });
-        static_for<0, kRows[k].en>([&](auto ec) {
-          const unsigned en = opaque(E[o + kRows[k].ee + ec.value]);
-          const double sc = ldsRead(ldsB, kTabBase + ENT_SCOFF(en));
-          d = dmax(d, ldsRead(ldsB, ENT_ADDR(en)) + sc);
-          s = dmax(s, ldsRead(ldsB, ENT_ADDR(en) + kCellBytes) + sc);
+        static_for<0, rowEN(k)>([&](auto ec) {
+          constexpr int cls = nullClass(k, ec.value);
+          const unsigned addr = E[o + rowEE(k) + ec.value];
+          double vd = ldsRead(ldsB, addr), vs = ldsRead(ldsB, addr + kCellBytes);
+          if constexpr (cls != 0) { vd = vd + scoreC[cls]; vs = vs + scoreC[cls]; }
+          d = dmax(d, vd);
+          s = dmax(s, vs);
         });
         s = dmax(s, d + a.delEnd);
         if (s != S[k] || d != Dv[k]) {
@@ -227,14 +257,14 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
           const double xv = dmax(d + a.delExtend, s + a.delOpen);
           X[k * T + tid] = xv;
           static_for<0, kRows[k].ec>([&](auto ec) {
-            const unsigned en = opaque(E[o + kRows[k].ee + kRows[k].en + kRows[k].ep + ec.value]);
+            const unsigned en = E[o + rowEE(k) + rowEN(k) + kRows[k].ep + ec.value];
             if (ENT_HASCELL(en)) {   // a heavy destination's cell also receives pushes: only ever raise it
               ldsMax(ldsB, ENT_ADDR(en) + kCellBytes, s);
               ldsMax(ldsB, ENT_ADDR(en), d);
             }
           });
           static_for<0, kRows[k].ep>([&](auto ec) {
-            const unsigned en = opaque(E[o + kRows[k].ee + kRows[k].en + ec.value]);
+            const unsigned en = E[o + rowEE(k) + rowEN(k) + ec.value];
             const double sc = ldsRead(ldsB, kTabBase + ENT_SCOFF(en));
             if (ENT_FLAG(en)) {
               ldsMax(ldsB, ENT_ADDR(en), xv + sc);
@@ -257,7 +287,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
       const double s = S[k];
       X[slot] = s;
       static_for<0, kRows[k].ec>([&](auto ec) {
-        const unsigned en = E[o + kRows[k].ee + kRows[k].en + kRows[k].ep + ec.value];
+        const unsigned en = E[o + rowEE(k) + rowEN(k) + kRows[k].ep + ec.value];
         if (ENT_HASCELL(en) && ENT_FLAG(en)) {
           ldsWrite(ldsB, ENT_ADDR(en) + kCellBytes, kNegInf);
           ldsWrite(ldsB, ENT_ADDR(en), kNegInf);
