@@ -9,6 +9,7 @@ constexpr int kMaxLen = 32;         // pLen entries (dnas_mutator_params.p_len)
 
 struct DevModel {
   int N, Npad, D, P, local;
+  int storedLanes;        // lanes per column in HBM: D+2 (tier B: S, D, T1..TD) or 2 (tier A: S, D; T recomputed)
   // in-edges per destination, reference enumeration order (traceback tie-break order)
   const int32_t* einPtr; const int32_t* einSrc; const double* einScore; const uint8_t* einBase; const uint8_t* einIn;
   const int32_t* ninPtr; const int32_t* ninSrc; const double* ninScore; const uint8_t* ninIn;

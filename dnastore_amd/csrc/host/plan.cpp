@@ -59,7 +59,7 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
   p.C = C;
   p.xDummy = p.NS + 2 * C;           // one extra double behind SN[], always -inf
   // X | DN | SN | -inf | score[4] sub[16] len[8] | red[T/64]
-  p.ldsBytes = (size_t)(p.NS + 2 * C + 1 + 28 + T / 64) * sizeof(double);
+  p.ldsBytes = (size_t)(p.NS + 2 * C + 1 + 28 + T / 64 + 2) * sizeof(double);   // + vote[3] (u32)
   if (p.ldsBytes > kTierALdsLimit) return no("LDS working set " + std::to_string(p.ldsBytes) + " B exceeds one CU");
 
   // pushes, filed under the source state

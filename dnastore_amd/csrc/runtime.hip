@@ -17,6 +17,7 @@
 
 extern "C" __global__ void viterbi_fill_kernel(DevModel, const uint8_t*, const uint64_t*, const int32_t*,
                                                const uint64_t*, double*, double*, unsigned long long*, int);
+extern "C" __global__ void expand_lattice_kernel(DevModel, const uint8_t*, const double*, double*);
 extern "C" __global__ void viterbi_traceback_kernel(DevModel, const uint8_t*, const uint64_t*, const int32_t*,
                                                     const uint64_t*, const double*, char*, const uint64_t*,
                                                     uint32_t*, uint8_t*, int);
@@ -73,6 +74,9 @@ struct dnas_model {
   size_t schedCap = 0;
   std::vector<uint64_t> lastSlotOff;   // host copy, sorted-batch order of the last call
   std::vector<int32_t> lastBatchRead;
+  std::vector<uint64_t> lastReadOff;   // host copy of the last call's read offsets
+  const uint8_t* lastBases = nullptr;  // device pointer of the last call's bases (valid while the caller keeps it)
+  uint8_t* keepBases = nullptr;        // dnas_viterbi_batch's own copy, kept until the next call (lattice export)
   std::vector<hipEvent_t> events;      // 3 per batch: start, after fill, after traceback
   dnas_batch_stats stats{};
   bool statsPending = false;
@@ -132,6 +136,7 @@ extern "C" int dnas_model_create(const dnas_flat_model* fm, int device_id, size_
   d.D = D;
   d.P = fm->n_len;
   d.local = fm->local;
+  d.storedLanes = D + 2;
   int rc;
 #define UP(field, src, n) if ((rc = upload(m, src, (size_t)(n), &d.field)) != DNAS_OK) return bail(rc)
   UP(einPtr, fm->ein_ptr, N + 1); UP(einSrc, fm->ein_src, fm->n_emit); UP(einScore, fm->ein_score, fm->n_emit);
@@ -147,7 +152,7 @@ extern "C" int dnas_model_create(const dnas_flat_model* fm, int device_id, size_
   memcpy(d.sub, fm->sub, sizeof d.sub);
   for (int k = 0; k < kMaxLen; ++k) d.len[k] = k < fm->n_len ? fm->len[k] : 0.;
   d.slotOf = nullptr;
-  if (hipMalloc((void**)&m->dRounds, sizeof(unsigned long long)) != hipSuccess)
+  if (hipMalloc((void**)&m->dRounds, 8 * sizeof(unsigned long long)) != hipSuccess)
     return bail(dnas::fail(DNAS_E_DEVICE, "hipMalloc failed"));
   // ---- tier A: specialise the register/LDS-resident kernel for this machine
   {
@@ -160,8 +165,10 @@ extern "C" int dnas_model_create(const dnas_flat_model* fm, int device_id, size_
         m->tierNote = "tier B: " + m->plan.whyNot;
       } else {
         try {
+          std::string defs = m->plan.defines;
+          if (const char* extra = getenv("DNAS_TIERA_DEFS")) defs += std::string("\n") + extra;   // diagnostics, e.g. -DDNAS_STAMP
           const std::vector<char> code =
-              dnas::jitCompile(dnas::libraryDir() + "/csrc/viterbi_tiera.hip", m->plan.defines, m->plan.key);
+              dnas::jitCompile(dnas::libraryDir() + "/csrc/viterbi_tiera.hip", defs, m->plan.key);
           if (hipModuleLoadData(&m->module, code.data()) != hipSuccess ||
               hipModuleGetFunction(&m->fillA, m->module, "viterbi_fill_tiera") != hipSuccess)
             throw std::runtime_error("hipModuleLoadData/GetFunction failed");
@@ -184,6 +191,7 @@ extern "C" int dnas_model_create(const dnas_flat_model* fm, int device_id, size_
           memcpy(a.score, p.score, sizeof a.score);
           d.slotOf = m->dSlotOf;
           d.Npad = p.NS;          // lattice row stride = slots
+          d.storedLanes = 2;      // tier A keeps S and D in HBM; T lanes are recomputed where needed
           m->tier = 1;
           m->tierNote = "tier A: " + p.key;
         } catch (const std::exception& e) {
@@ -209,6 +217,7 @@ extern "C" void dnas_model_destroy(dnas_model* m) {
   for (void* p : m->owned) (void)hipFree(p);
   if (m->arena) (void)hipFree(m->arena);
   if (m->dRounds) (void)hipFree(m->dRounds);
+  if (m->keepBases) (void)hipFree(m->keepBases);
   if (m->dEntTab) (void)hipFree(m->dEntTab);
   if (m->dMetaTab) (void)hipFree(m->dMetaTab);
   if (m->dBaseTab) (void)hipFree(m->dBaseTab);
@@ -251,7 +260,7 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
   if (n_reads == 0) return DNAS_OK;
   const DevModel& d = m->dm;
   const size_t lanes = (size_t)d.D + 2;
-  const size_t colDoubles = lanes * (size_t)d.Npad;
+  const size_t colDoubles = (size_t)d.storedLanes * (size_t)d.Npad;
 
   // longest reads first: a batch's work-groups then finish together
   std::vector<int32_t> order((size_t)n_reads);
@@ -301,12 +310,14 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
   }
   m->lastSlotOff = slotOff;
   m->lastBatchRead = order;
+  m->lastReadOff.assign(read_offsets, read_offsets + n_reads + 1);
+  m->lastBases = d_bases;
   // host vectors stay alive until the copies complete (synchronous copies keep this simple)
   HIP_TRY(hipMemcpy(m->dBatchRead, order.data(), (size_t)n_reads * sizeof(int32_t), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(m->dSlotOff, slotOff.data(), (size_t)n_reads * sizeof(uint64_t), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(m->dReadOff, read_offsets, ((size_t)n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(m->dOutOff, out_offsets, ((size_t)n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemsetAsync(m->dRounds, 0, sizeof(unsigned long long), m->stream));
+  HIP_TRY(hipMemsetAsync(m->dRounds, 0, 8 * sizeof(unsigned long long), m->stream));
 
   const size_t nBatches = batchStart.size() - 1;
   while (m->events.size() < 3 * nBatches) {
@@ -366,10 +377,12 @@ extern "C" int dnas_viterbi_batch(dnas_model* m, int64_t n_reads, const uint64_t
   for (size_t i = 0; i < nBases; ++i)
     if (bases[i] > 3) return dnas::fail(DNAS_E_BAD_BASE, "base code > 3 at offset " + std::to_string(i));
   const size_t nOut = (size_t)out_offsets[n_reads];
+  if (m->keepBases) { (void)hipFree(m->keepBases); m->keepBases = nullptr; m->lastBases = nullptr; }
   uint8_t* dBases = nullptr; char* dSym = nullptr; uint32_t* dLen = nullptr; double* dLL = nullptr; uint8_t* dSt = nullptr;
   int rc = DNAS_OK;
+  bool keep = false;
   auto cleanup = [&]() {
-    if (dBases) (void)hipFree(dBases);
+    if (dBases && !keep) (void)hipFree(dBases);
     if (dSym) (void)hipFree(dSym);
     if (dLen) (void)hipFree(dLen);
     if (dLL) (void)hipFree(dLL);
@@ -394,35 +407,34 @@ extern "C" int dnas_viterbi_batch(dnas_model* m, int64_t n_reads, const uint64_t
   TRY_OR_CLEAN(hipMemcpy(out_loglike, dLL, (size_t)n_reads * sizeof(double), hipMemcpyDeviceToHost));
   TRY_OR_CLEAN(hipMemcpy(out_status, dSt, (size_t)n_reads, hipMemcpyDeviceToHost));
 #undef TRY_OR_CLEAN
+  keep = true;
+  m->keepBases = dBases;
   cleanup();
   return DNAS_OK;
 }
 
 extern "C" int dnas_model_read_lattice(dnas_model* m, int64_t slot, int64_t len, double* out) {
-  if (!m || !out || slot < 0 || (size_t)slot >= m->lastSlotOff.size() || len < 0)
+  if (!m || !out || slot < 0 || len < 0 || m->lastReadOff.empty() || (size_t)slot + 1 >= m->lastReadOff.size())
     return dnas::fail(DNAS_E_INVALID, "dnas_model_read_lattice: bad argument");
   HIP_TRY(hipSetDevice(m->device));
   HIP_TRY(hipStreamSynchronize(m->stream));
   const DevModel& d = m->dm;
   const size_t lanes = (size_t)d.D + 2;
-  // `slot` indexes the caller's read order; find its arena slot
+  // `slot` indexes the caller's read order; find its arena slot (valid for the last batch of the call)
   size_t pos = 0;
   for (; pos < m->lastBatchRead.size(); ++pos)
     if (m->lastBatchRead[pos] == (int32_t)slot) break;
   if (pos == m->lastBatchRead.size()) return dnas::fail(DNAS_E_INVALID, "no such read in the last batch");
-  const double* src = m->arena + m->lastSlotOff[pos];
-  if (m->tier == 1) {
-    // slot order -> state order
-    const size_t rows = (size_t)(len + 1) * lanes, NS = (size_t)d.Npad;
-    std::vector<double> tmp(rows * NS);
-    HIP_TRY(hipMemcpy(tmp.data(), src, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
-    for (size_t r = 0; r < rows; ++r)
-      for (int j = 0; j < d.N; ++j) out[r * (size_t)d.N + j] = tmp[r * NS + (size_t)m->plan.slotOf[j]];
-    return DNAS_OK;
-  }
-  // strip the row padding: [pos][lane][Npad] -> [pos][lane][N]
-  HIP_TRY(hipMemcpy2D(out, (size_t)d.N * sizeof(double), src, (size_t)d.Npad * sizeof(double),
-                      (size_t)d.N * sizeof(double), (size_t)(len + 1) * lanes, hipMemcpyDeviceToHost));
+  if ((uint64_t)len != m->lastReadOff[slot + 1] - m->lastReadOff[slot]) return dnas::fail(DNAS_E_INVALID, "length mismatch");
+  const size_t n = (size_t)(len + 1) * lanes * (size_t)d.N;
+  double* dOut = nullptr;
+  HIP_TRY(hipMalloc((void**)&dOut, n * sizeof(double)));
+  hipLaunchKernelGGL(expand_lattice_kernel, dim3((unsigned)(len + 1)), dim3(256), 0, m->stream, d,
+                     m->lastBases + m->lastReadOff[slot], (const double*)(m->arena + m->lastSlotOff[pos]), dOut);
+  hipError_t e = hipStreamSynchronize(m->stream);
+  if (e == hipSuccess) e = hipMemcpy(out, dOut, n * sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipFree(dOut);
+  if (e != hipSuccess) return dnas::fail(DNAS_E_DEVICE, hipGetErrorString(e));
   return DNAS_OK;
 }
 
@@ -447,3 +459,12 @@ extern "C" int dnas_tiera_precompile(const dnas_flat_model* fm, char* note, size
 }
 
 extern "C" const char* dnas_model_tier(const dnas_model* m) { return m ? m->tierNote.c_str() : ""; }
+
+// Diagnostic: the 8 words of the rounds/stamps buffer of the last call (word 0 = total rounds).
+extern "C" int dnas_model_debug_words(dnas_model* m, unsigned long long* out8) {
+  if (!m || !out8) return dnas::fail(DNAS_E_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  HIP_TRY(hipMemcpy(out8, m->dRounds, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return DNAS_OK;
+}

@@ -65,7 +65,39 @@ __device__ __forceinline__ void mark_successors(const DevModel& m, int j, unsign
   }
 }
 
+// One lattice cell, whatever the storage tier.  With storedLanes == 2 the duplication lanes
+// are not in memory; T(p,q) = max(T(p-1,q+1) + sub[ctx[q+1]][x_p], (S(p)+tanDup)+len[q]),
+// T(0,.) = -inf (viterbi.cpp:105-106,161-168) is rebuilt from the state's own S cells, deepest
+// element first -- the same fp64 operations in the same order as the fill, hence the same bits.
+__device__ __forceinline__ double lattice_cell(const DevModel& m, const double* __restrict__ lat,
+                                               const uint8_t* __restrict__ seq, int st, int ps, int ln) {
+  const size_t stride = (size_t)m.Npad;
+  const size_t slot = (size_t)(m.slotOf ? m.slotOf[st] : st);
+  if (ln < 2 || m.storedLanes > 2) return lat[((size_t)ps * m.storedLanes + (size_t)ln) * stride + slot];
+  const int k = ln - 2, mdl = m.mdl[st];
+  if (ps < 1 || k >= mdl) return kNegInf;
+  const uint8_t* ctx = m.ctx + (size_t)st * m.D;
+  int I = mdl - 1 - k;
+  if (ps - 1 < I) I = ps - 1;
+  double v = (lat[((size_t)(ps - I) * 2) * stride + slot] + m.tanDup) + m.len[k + I];
+  for (int i = I - 1; i >= 0; --i) {
+    const int p = ps - i, q = k + i;
+    v = dmax(v + m.sub[ctx[q + 1] * 4 + seq[p - 1]], (lat[((size_t)p * 2) * stride + slot] + m.tanDup) + m.len[q]);
+  }
+  return v;
+}
+
 }  // namespace
+
+// Test/diagnostic aid: the full (D+2)-lane lattice of one read in reference state order,
+// out[(pos*(D+2)+lane)*N + state], whatever the storage tier.  grid = L+1, any block size.
+extern "C" __global__ void expand_lattice_kernel(DevModel m, const uint8_t* __restrict__ seq, const double* __restrict__ lat,
+                                                 double* __restrict__ out) {
+  const int ps = blockIdx.x, lanes = m.D + 2;
+  for (int st = threadIdx.x; st < m.N; st += blockDim.x)
+    for (int ln = 0; ln < lanes; ++ln)
+      out[((size_t)ps * lanes + ln) * m.N + st] = lattice_cell(m, lat, seq, st, ps, ln);
+}
 
 // grid = reads in this batch, block = kFillThreads.
 // Dynamic LDS: two dirty-state bitmasks of maskWords 32-bit words each.
@@ -196,14 +228,12 @@ viterbi_traceback_kernel(DevModel m, const uint8_t* __restrict__ bases, const ui
   const uint8_t* seq = bases + readOff[read];
   const int L = (int)(readOff[read + 1] - readOff[read]);
   const double* lat = arena + slotOff[b];
-  const int N = m.N, D_ = m.D, lanes = m.D + 2;
-  const size_t Npad = (size_t)m.Npad;
-  const int32_t* __restrict__ slotOf = m.slotOf;
+  const int N = m.N, D_ = m.D;
   char* out = outSym + outOff[read];
   const long cap = (long)(outOff[read + 1] - outOff[read]);
   long n = 0;
 
-#define CELL(st, ps, ln) lat[((size_t)(ps) * lanes + (size_t)(ln)) * Npad + (size_t)(slotOf ? slotOf[st] : (st))]
+#define CELL(st, ps, ln) lattice_cell(m, lat, seq, (st), (ps), (ln))
   if (!(CELL(N - 1, L, 0) > kNegInf)) {  // viterbi.cpp:198-201
     outLen[read] = 0;
     outStatus[read] = 1;  // DNAS_READ_NO_PATH

@@ -52,6 +52,12 @@ constexpr int nullClass(int k, int e) {
   return c;
 }
 constexpr int kEntries = rowOffset(DNAS_K) > 0 ? rowOffset(DNAS_K) : 1;
+constexpr int maxRowVals() {
+  int m = 0;
+  for (int k = 0; k < DNAS_K; ++k) m = rowEE(k) + 2 * rowEN(k) > m ? rowEE(k) + 2 * rowEN(k) : m;
+  return m;
+}
+constexpr int kMaxRowVals = maxRowVals();
 
 template <int V> struct IntC { static constexpr int value = V; };
 template <int I, int N, class F>
@@ -72,7 +78,7 @@ struct TierAArgs {
   double score[4];  // score table, score[0] == 0
 };
 
-// LDS map (bytes):  X[NS] | DN[C] | SN[C] | negInf | score[4] | sub[16] | len[8] | red[T/64]
+// LDS map (bytes):  X[NS] | DN[C] | SN[C] | negInf | score[4] | sub[16] | len[8] | red[T/64] | vote[3] (u32)
 constexpr int kXBytes = DNAS_NS * 8;
 constexpr int kCellBytes = DNAS_C * 8;           // SN[cell] sits kCellBytes behind DN[cell]
 constexpr int kTabBase = kXBytes + 2 * kCellBytes + 8;
@@ -125,12 +131,13 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
                    double* __restrict__ arena, double* __restrict__ outLoglike,
                    unsigned long long* __restrict__ roundsTotal) {
   extern __shared__ double lds[];
-  constexpr int T = DNAS_T, K = DNAS_K, D_ = DNAS_D, lanes = DNAS_D + 2, NS = DNAS_NS;
+  constexpr int T = DNAS_T, K = DNAS_K, D_ = DNAS_D, lanes = 2, NS = DNAS_NS;   // stored lanes: S, D
   const int tid = threadIdx.x;
   char* const ldsB = reinterpret_cast<char*>(lds);
   double* const X = lds;
   const double* const subL = lds + (kTabBase / 8) + 4;
   const double* const lenL = subL + 16;
+  volatile unsigned* const voteL = reinterpret_cast<volatile unsigned*>(lds + (kTabBase / 8) + 28 + DNAS_T / 64);
 
   const int read = batchRead[blockIdx.x];
   const unsigned char* seq = bases + readOff[read];
@@ -142,25 +149,34 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
 #define META(k) (metaTab[(size_t)(k) * T + tid])
   const double scoreC[4] = {0.0, a.score[1], a.score[2], a.score[3]};
 
-  double S[K], Dv[K];
+  double S[K], Dv[K], tc[K];
   unsigned rounds = 0;
+#ifdef DNAS_STAMP   // diagnostic build: where does a column spend its cycles (never in the shipped kernel)
+  unsigned long long tA = 0, tP = 0, tB = 0, tC = 0, t0 = 0, t1 = 0;
+#define STAMP(acc) { t1 = __builtin_amdgcn_s_memtime(); acc += t1 - t0; t0 = t1; }
+#else
+#define STAMP(acc)
+#endif
 
   // LDS init: everything -inf (dummy cells / slots stay that way), then the small tables
   for (int i = tid; i < NS + 2 * DNAS_C + 1; i += T) lds[i] = kNegInf;
   if (tid < 4) lds[kTabBase / 8 + tid] = a.score[tid];
   if (tid < 16) lds[kTabBase / 8 + 4 + tid] = a.sub[tid];
   if (tid < 8) lds[kTabBase / 8 + 20 + tid] = a.len[tid];
+  if (tid < 3) voteL[tid] = 0;
   __syncthreads();
 
   for (int pos = 0; pos <= L; ++pos) {
     double* const col = lat + (size_t)pos * lanes * NS;
-    const double* const prev = col - (size_t)lanes * NS;
     const int x = pos > 0 ? seq[pos - 1] : 0;
+#ifdef DNAS_STAMP
+    t0 = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- phase A (viterbi.cpp:75-79,92-95,101-103): S of this column from the previous
-    // column's S (parked in X[] by the previous iteration) and the T1 lane.  Heavy
-    // destinations receive their emit-in candidates by ds_max pushes into SN[cell] (their
-    // owners reset the cell at the end of the previous column).
+    // column's S (parked in X[] by phase C) and the T1 lane (handed over in tc[] by phase C).
+    // Heavy destinations receive their emit-in candidates by ds_max pushes into SN[cell]
+    // (their owners reset the cell in phase C).
     if (pos > 0) {
       static_for<0, K>([&](auto kc) {
         constexpr int k = kc.value, o = rowOffset(k);
@@ -172,29 +188,32 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
           }
         });
       });
-    }
-    static_for<0, K>([&](auto kc) {
-      constexpr int k = kc.value, o = rowOffset(k);
-      const int slot = k * T + tid;
-      const unsigned meta = META(k);
-      double s;
-      if (pos == 0) {
-        s = (slot < a.N && (a.local || (meta & 0x80000000u))) ? 0.0 : kNegInf;   // bit31: reference state 0
-      } else {
-        s = kNegInf;
-        const unsigned bases = rowEE(k) > 0 ? baseTab[(size_t)k * T + tid] : 0u;
+      unsigned bases[K];
+      static_for<0, K>([&](auto kc) {
+        constexpr int k = kc.value;
+        if constexpr (rowEE(k) > 0) bases[k] = baseTab[(size_t)k * T + tid];
+      });
+      static_for<0, K>([&](auto kc) {
+        constexpr int k = kc.value, o = rowOffset(k);
+        double s = tc[k];
         static_for<0, rowEE(k)>([&](auto ec) {
           constexpr int cls = emitClass(k, ec.value);
           // (S(src) + score) + noGap + sub: "+ 0.0" of class 0 is the identity on every value that occurs
           double v = ldsRead(ldsB, E[o + ec.value]);
           if constexpr (cls != 0) v = v + scoreC[cls];
-          s = dmax(s, (v + a.noGap) + subL[((bases >> (2 * ec.value)) & 3u) * 4 + x]);
+          s = dmax(s, (v + a.noGap) + subL[((bases[k] >> (2 * ec.value)) & 3u) * 4 + x]);
         });
-        if ((meta & 15u) > 0 && slot < a.N) s = dmax(s, prev[(size_t)2 * NS + slot] + subL[((meta >> 4) & 3u) * 4 + x]);
-      }
-      S[k] = s;
-    });
+        S[k] = s;
+      });
+    } else {
+      static_for<0, K>([&](auto kc) {
+        constexpr int k = kc.value;
+        const int slot = k * T + tid;
+        S[k] = (slot < a.N && (a.local || (META(k) & 0x80000000u))) ? 0.0 : kNegInf;   // viterbi.cpp:75-79; bit31: state 0
+      });
+    }
     __syncthreads();   // every gather of the previous column (and every phase-A push) is done
+    STAMP(tA)
 
     // ---- start of the fixpoint: D = -inf, X = max(D+delExtend, S+delOpen); cells published;
     // every push edge fired once with the starting values
@@ -228,23 +247,39 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
       });
     });
     __syncthreads();
+    STAMP(tP)
 
-    // ---- phase B: sweeps to the fixpoint (viterbi.cpp:97-99,110-159)
-    for (;;) {
+    // ---- phase B: sweeps to the fixpoint (viterbi.cpp:97-99,110-159).  The LDS reads of row
+    // k+1 are issued before row k is evaluated (software pipeline: the gather latency hides
+    // behind the previous row's arithmetic); one barrier per sweep, the "did anything grow"
+    // vote goes through three rotating LDS words.
+    for (unsigned sweep = 0;; ++sweep) {
       int changed = 0;
+      double buf[2][kMaxRowVals > 0 ? kMaxRowVals : 1];
+      auto issue = [&](auto kc) {
+        constexpr int k = kc.value, o = rowOffset(k), b = k & 1;
+        static_for<0, rowEE(k)>([&](auto ec) { buf[b][ec.value] = ldsRead(ldsB, E[o + ec.value]); });
+        static_for<0, rowEN(k)>([&](auto ec) {
+          const unsigned addr = E[o + rowEE(k) + ec.value];
+          buf[b][rowEE(k) + 2 * ec.value] = ldsRead(ldsB, addr);
+          buf[b][rowEE(k) + 2 * ec.value + 1] = ldsRead(ldsB, addr + kCellBytes);
+        });
+      };
+      if (tid == 0) voteL[(sweep + 1) % 3] = 0;
+      issue(IntC<0>{});
       static_for<0, K>([&](auto kc) {
-        constexpr int k = kc.value, o = rowOffset(k);
+        constexpr int k = kc.value, o = rowOffset(k), b = k & 1;
+        if constexpr (k + 1 < K) issue(IntC<k + 1>{});
         double s = S[k], d = Dv[k];
         static_for<0, rowEE(k)>([&](auto ec) {
           constexpr int cls = emitClass(k, ec.value);
-          double v = ldsRead(ldsB, E[o + ec.value]);
+          double v = buf[b][ec.value];
           if constexpr (cls != 0) v = v + scoreC[cls];
           d = dmax(d, v);
         });
         static_for<0, rowEN(k)>([&](auto ec) {
           constexpr int cls = nullClass(k, ec.value);
-          const unsigned addr = E[o + rowEE(k) + ec.value];
-          double vd = ldsRead(ldsB, addr), vs = ldsRead(ldsB, addr + kCellBytes);
+          double vd = buf[b][rowEE(k) + 2 * ec.value], vs = buf[b][rowEE(k) + 2 * ec.value + 1];
           if constexpr (cls != 0) { vd = vd + scoreC[cls]; vs = vs + scoreC[cls]; }
           d = dmax(d, vd);
           s = dmax(s, vs);
@@ -276,42 +311,80 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
         }
       });
       ++rounds;
-      if (!__syncthreads_or(changed)) break;
+      if (__any(changed) && (tid & 63) == 0) voteL[sweep % 3] = 1;
+      __syncthreads();
+      if (!voteL[sweep % 3]) break;
     }
+    STAMP(tB)
 
-    // ---- phase C: duplication lanes (viterbi.cpp:105-106,161-168), lattice stores in slot
-    // order (coalesced), S parked in X[] for the next column's gathers, heavy cells reset
-    static_for<0, K>([&](auto kc) {
-      constexpr int k = kc.value, o = rowOffset(k);
-      const int slot = k * T + tid;
-      const double s = S[k];
-      X[slot] = s;
-      static_for<0, kRows[k].ec>([&](auto ec) {
-        const unsigned en = E[o + rowEE(k) + rowEN(k) + kRows[k].ep + ec.value];
-        if (ENT_HASCELL(en) && ENT_FLAG(en)) {
-          ldsWrite(ldsB, ENT_ADDR(en) + kCellBytes, kNegInf);
-          ldsWrite(ldsB, ENT_ADDR(en), kNegInf);
-        }
-      });
-      if (slot < a.N) {
-        const unsigned meta = META(k);
-        const unsigned mdl = meta & 15u;
-        col[slot] = s;
-        col[(size_t)NS + slot] = Dv[k];
-        static_for<0, D_>([&](auto qc) {
-          constexpr int q = qc.value;
-          double t = kNegInf;
-          if (pos > 0 && (unsigned)q < mdl) {
-            if ((unsigned)q + 1 < mdl)
-              t = prev[(size_t)(3 + q) * NS + slot] + subL[((meta >> (4 + 2 * (q + 1))) & 3u) * 4 + x];
-            t = dmax(t, (s + a.tanDup) + lenL[q]);
+    // ---- phase C: the column's S and D lanes go to HBM in slot order (coalesced); S is parked
+    // in X[] for the next column's gathers; heavy cells are reset.  The duplication lanes
+    // T1..TD (viterbi.cpp:105-106,161-168) are NOT stored: T(pos,q) is a function of this
+    // state's own S(pos), S(pos-1), ... S(pos-(D-1)) and the read,
+    //     T(p,q) = max( T(p-1,q+1) + sub[ctx[q+1]][x_p],  (S(p)+tanDup)+len[q] ),   T(0,.) = -inf,
+    // and fp max/+ satisfy max(a,b)+c == max(a+c,b+c) exactly, so evaluating the chain from
+    // its deepest element reproduces the reference's cell bit for bit.  Only T1(pos) is needed
+    // here (it feeds S of the next column, viterbi.cpp:101-103); the traceback kernel rebuilds
+    // any T cell it visits the same way.  The S history comes back from HBM/L2 (this thread
+    // wrote it), a group of rows per memory latency.
+    {
+      const int xn = pos < L ? seq[pos] : 0;
+      unsigned meta[K];
+      static_for<0, K>([&](auto kc) { meta[kc.value] = META(kc.value); });
+      int xh[D_ > 0 ? D_ : 1];   // xh[i] = x_{pos-i}
+      static_for<0, D_>([&](auto ic) { xh[ic.value] = pos - ic.value >= 1 ? seq[pos - ic.value - 1] : 0; });
+      constexpr int G = 4;
+      static_for<0, (K + G - 1) / G>([&](auto gc) {
+        constexpr int k0 = gc.value * G, k1 = (k0 + G < K) ? k0 + G : K;
+        double sh[G][D_ > 1 ? D_ - 1 : 1];
+        static_for<1, D_>([&](auto ic) {
+          constexpr int i = ic.value;
+          if (pos - i >= 1) {
+            static_for<k0, k1>([&](auto kc) { sh[kc.value - k0][i - 1] = (col - (size_t)i * lanes * NS)[kc.value * T + tid]; });
           }
-          col[(size_t)(2 + q) * NS + slot] = t;
         });
-      }
-    });
+        static_for<k0, k1>([&](auto kc) {
+          constexpr int k = kc.value, o = rowOffset(k);
+          const int slot = k * T + tid;
+          const double s = S[k];
+          const int mdl = (int)(meta[k] & 15u);
+          X[slot] = s;
+          static_for<0, kRows[k].ec>([&](auto ec) {
+            const unsigned en = E[o + rowEE(k) + rowEN(k) + kRows[k].ep + ec.value];
+            if (ENT_HASCELL(en) && ENT_FLAG(en)) {
+              ldsWrite(ldsB, ENT_ADDR(en) + kCellBytes, kNegInf);
+              ldsWrite(ldsB, ENT_ADDR(en), kNegInf);
+            }
+          });
+          if (slot < a.N) {
+            col[slot] = s;
+            col[(size_t)NS + slot] = Dv[k];
+          }
+          // T1(pos): chain from the deepest element (i = D-1) to i = 0
+          double v = kNegInf;
+          static_for<0, D_>([&](auto jc) {
+            constexpr int i = D_ - 1 - jc.value;           // lane q = i at column p = pos - i
+            if (i < mdl && pos - i >= 1) {
+              double sp = s;
+              if constexpr (i > 0) sp = sh[k - k0][i - 1];
+              const double base = (sp + a.tanDup) + lenL[i];
+              if (i + 1 < mdl && pos - i - 1 >= 1)
+                v = dmax(v + subL[((meta[k] >> (4 + 2 * (i + 1))) & 3u) * 4 + xh[i]], base);
+              else
+                v = base;
+            }
+          });
+          // next column: S >= T1(pos) + sub[ctx1][x_{pos+1}]   (viterbi.cpp:101-103)
+          tc[k] = (mdl > 0) ? v + subL[((meta[k] >> 4) & 3u) * 4 + xn] : kNegInf;
+        });
+      });
+    }
     __syncthreads();   // X[] now holds S(pos) for everyone
+    STAMP(tC)
   }
+#ifdef DNAS_STAMP
+  if (tid == 0 && blockIdx.x == 0) { roundsTotal[1] = tA; roundsTotal[2] = tP; roundsTotal[3] = tB; roundsTotal[4] = tC; roundsTotal[5] = (unsigned long long)rounds; }
+#endif
 
   // ---- loglike (viterbi.h:102); local mode overwrites the end state with the column max
   // (viterbi.cpp:171-173).  bit30 of meta marks the reference's last state.

@@ -148,6 +148,10 @@ const char *dnas_model_tier(const dnas_model *model);
 /* Specialise + compile the tier-A kernel for a machine ahead of time (no GPU needed). */
 int dnas_tiera_precompile(const dnas_flat_model *fm, char *note, size_t note_cap);
 
+/* Diagnostic: 8 words of the kernel's rounds/stamp buffer (word 0 = total rounds; words 1-5 are filled only by
+ * a -DDNAS_STAMP diagnostic build selected with DNAS_TIERA_DEFS). */
+int dnas_model_debug_words(dnas_model *model, unsigned long long *out8);
+
 /* Device-time accounting of the last batch call (HIP events on the model's stream). */
 typedef struct dnas_batch_stats {
   double fill_ms, traceback_ms;   /* summed kernel durations          */
