@@ -12,7 +12,7 @@ namespace {
 constexpr int kHeavy = 4;  // destinations with more in-edges than this are fed by pushes
 
 struct Pull { int src; int sc; int base; };
-struct Push { int dstCell; int sc; int base; int emit; };
+struct Push { int dst; int sc; int base; int emit; };
 
 }  // namespace
 
@@ -53,21 +53,23 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
   }
   std::vector<int> cellOf(N, -1);
   int nCells = 0;
-  for (int j = 0; j < N; ++j) if (hasCell[j]) cellOf[j] = nCells++;
-  const int C = nCells + 2;          // + write-dummy (C-2) + read-dummy (C-1)
+  for (int j = 0; j < N; ++j) if (hasCell[j]) ++nCells;
+  // cells are numbered after the lanes are known (bank-aware); C is padded to a multiple of 32
+  // so that SN[cell] and DN[cell] fall on the same LDS bank pair
+  const int C = ((nCells + 2 + 31) / 32) * 32;   // + write-dummy (C-2) + read-dummy (C-1)
   const int readDummy = C - 1, writeDummy = C - 2;
   p.C = C;
   p.xDummy = p.NS + 2 * C;           // one extra double behind SN[], always -inf
-  // X | DN | SN | -inf | score[4] sub[16] len[8] | red[T/64]
-  p.ldsBytes = (size_t)(p.NS + 2 * C + 1 + 28 + T / 64 + 2) * sizeof(double);   // + vote[3] (u32)
+  // X | DN | SN | -inf | score[4] sub[16] len[8] | red[T/64] | vote[3]
+  p.ldsBytes = (size_t)(p.NS + 2 * C + 1 + 28 + T / 64 + 2) * sizeof(double);
   if (p.ldsBytes > kTierALdsLimit) return no("LDS working set " + std::to_string(p.ldsBytes) + " B exceeds one CU");
 
   // pushes, filed under the source state
   std::vector<std::vector<Push>> pushes(N);
   for (int j = 0; j < N; ++j)
     if (heavy[j]) {
-      for (const Pull& q : emitIn[j]) pushes[q.src].push_back({cellOf[j], q.sc, q.base, 1});
-      for (const Pull& q : nullIn[j]) pushes[q.src].push_back({cellOf[j], q.sc, 0, 0});
+      for (const Pull& q : emitIn[j]) pushes[q.src].push_back({j, q.sc, q.base, 1});
+      for (const Pull& q : nullIn[j]) pushes[q.src].push_back({j, q.sc, 0, 0});
     }
 
   // per-state entry counts: emit/null pulls by score class, pushes, publish
@@ -94,9 +96,77 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
   std::vector<int> order(N);
   std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sortKey(cnt[a]) > sortKey(cnt[b]); });
+  // Lane placement inside each row.  LDS is 64 banks of 4 bytes and a ds_read_b64 is served in
+  // two 32-lane halves, so a gather is conflict-free when the 32 source slots of a half fall on
+  // 32 different bank pairs, i.e. have different (slot mod 32) = (lane mod 32).  Putting a state
+  // on the lane of its first emit source (or at least on the same lane mod 32) makes the
+  // gathers of chain-like machines conflict-free, and keeps a chain inside one thread.
+  std::vector<int> laneOf(N, -1), rowOfState(N, -1);
+  for (int i = 0; i < N; ++i) rowOfState[order[i]] = i / T;
+  for (int i = 0; i < N; ++i) laneOf[order[i]] = i % T;          // initial: sort order
+  for (int pass = 0; pass < 3; ++pass) {
+    for (int k = 0; k < K; ++k) {
+      const int lo = k * T, hi = std::min(N, (k + 1) * T);
+      std::vector<int> lanesFree(T, 1), pending;
+      std::vector<int> newLane(hi - lo, -1);
+      // exact lane of the primary source first, then same residue, then anything
+      for (int i = lo; i < hi; ++i) {
+        const int j = order[i];
+        const int src = (!heavy[j] && !emitIn[j].empty()) ? emitIn[j][0].src : -1;
+        if (src >= 0 && src != j && lanesFree[laneOf[src]]) { newLane[i - lo] = laneOf[src]; lanesFree[laneOf[src]] = 0; }
+      }
+      for (int i = lo; i < hi; ++i) {
+        if (newLane[i - lo] >= 0) continue;
+        const int j = order[i];
+        const int src = (!heavy[j] && !emitIn[j].empty()) ? emitIn[j][0].src : -1;
+        if (src >= 0 && src != j) {
+          const int r = laneOf[src] % 32;
+          for (int t = r; t < T; t += 32)
+            if (lanesFree[t]) { newLane[i - lo] = t; lanesFree[t] = 0; break; }
+        }
+      }
+      int cursor = 0;
+      for (int i = lo; i < hi; ++i) {
+        if (newLane[i - lo] >= 0) continue;
+        while (!lanesFree[cursor]) ++cursor;
+        newLane[i - lo] = cursor;
+        lanesFree[cursor] = 0;
+      }
+      for (int i = lo; i < hi; ++i) laneOf[order[i]] = newLane[i - lo];
+    }
+  }
   p.slotOf.assign(N, -1);
   p.stateOf.assign(p.NS, -1);
-  for (int i = 0; i < N; ++i) { p.slotOf[order[i]] = i; p.stateOf[i] = order[i]; }
+  for (int j = 0; j < N; ++j) {
+    const int slot = rowOfState[j] * T + laneOf[j];
+    p.slotOf[j] = slot;
+    p.stateOf[slot] = j;
+  }
+  // cell numbering: a null pull reads DN/SN[cell(src)]; give the cell the bank pair of its first
+  // consumer's lane, buckets balanced so that C does not grow
+  {
+    std::vector<int> want(N, -1);
+    for (int j = 0; j < N; ++j)
+      if (!heavy[j])
+        for (const Pull& q : nullIn[j])
+          if (want[q.src] < 0) want[q.src] = laneOf[j] % 32;
+    const int perBucket = (C - 2) / 32;                   // capacity of each residue class below the dummies
+    std::vector<int> fill(32, 0);
+    auto take = [&](int r) { const int id = r + 32 * fill[r]; ++fill[r]; return id; };
+    std::vector<int> later;
+    for (int j = 0; j < N; ++j) {
+      if (!hasCell[j]) continue;
+      const int r = want[j];
+      if (r >= 0 && fill[r] < perBucket) cellOf[j] = take(r); else later.push_back(j);
+    }
+    int r = 0;
+    for (int j : later) {
+      while (fill[r] >= perBucket + (r < (C - 2) % 32 ? 1 : 0)) r = (r + 1) % 32;
+      cellOf[j] = take(r);
+    }
+    for (int j = 0; j < N; ++j)
+      if (hasCell[j] && cellOf[j] >= C - 2) return no("internal: cell numbering overflow");
+  }
 
   p.rows.assign(K, RowShape{{0, 0, 0, 0}, {0, 0, 0, 0}, 0, 0});
   long real = 0;
@@ -163,7 +233,7 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
       for (int e = 0; e < r.ep; ++e, ++m) {
         unsigned v = packed(dnBase + (unsigned)writeDummy, 0, 0, 0, 0);
         if (j >= 0 && e < (int)pushes[j].size())
-          v = packed(dnBase + (unsigned)pushes[j][e].dstCell, pushes[j][e].sc, pushes[j][e].base, pushes[j][e].emit, 0);
+          v = packed(dnBase + (unsigned)cellOf[pushes[j][e].dst], pushes[j][e].sc, pushes[j][e].base, pushes[j][e].emit, 0);
         p.entTab[(size_t)m * T + t] = v;
       }
       for (int e = 0; e < r.ec; ++e, ++m) {
@@ -177,11 +247,44 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
         for (int q = 0; q < fm.mdl[j] && q < 8; ++q) meta |= (unsigned)(fm.ctx[(size_t)j * D + q] & 3u) << (4 + 2 * q);
         if (j == 0) meta |= 0x80000000u;
         if (j == N - 1) meta |= 0x40000000u;
+        meta |= 0x20000000u;   // slot holds a real state
       }
       p.metaTab[(size_t)k * T + t] = meta;
       p.baseTab[(size_t)k * T + t] = bases;
     }
     off += rowEntries(r);
+  }
+
+  // LDS cost model of one sweep's gathers: a ds_read_b64 is served per 32-lane half in as many
+  // cycles as the most loaded bank pair ((addr/8) mod 32) has distinct addresses
+  {
+    long cyc = 0, ideal = 0;
+    int o2 = 0;
+    for (int k = 0; k < K; ++k) {
+      const RowShape& r = p.rows[k];
+      const int pulls = r.e[0] + r.e[1] + r.e[2] + r.e[3] + r.n[0] + r.n[1] + r.n[2] + r.n[3];
+      const int nE = r.e[0] + r.e[1] + r.e[2] + r.e[3];
+      for (int e = 0; e < pulls; ++e) {
+        for (int h = 0; h < T / 32; ++h) {
+          int load[32] = {0};
+          std::vector<unsigned> seen[32];
+          for (int l = 0; l < 32; ++l) {
+            const unsigned addr = p.entTab[(size_t)(o2 + e) * T + h * 32 + l];
+            const unsigned b = (addr / 8) % 32;
+            bool dup = false;
+            for (unsigned a2 : seen[b]) if (a2 == addr) dup = true;
+            if (!dup) { seen[b].push_back(addr); ++load[b]; }
+          }
+          int mx = 1;
+          for (int b = 0; b < 32; ++b) mx = std::max(mx, load[b]);
+          cyc += (e < nE ? 1 : 2) * mx;      // a null pull reads DN and SN
+          ideal += (e < nE ? 1 : 2);
+        }
+      }
+      o2 += pulls + r.ep + r.ec;
+    }
+    p.ldsCycles = cyc;
+    p.ldsCyclesIdeal = ideal;
   }
 
   std::ostringstream rows, defs;

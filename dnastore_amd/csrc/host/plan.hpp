@@ -37,6 +37,7 @@ struct TierAPlan {
   double score[4] = {0, 0, 0, 0};
   size_t ldsBytes = 0;
   double fillRatio = 0;           // real entries / padded entries
+  long ldsCycles = 0, ldsCyclesIdeal = 0;   // modelled LDS cycles of one sweep's gathers (with / without bank conflicts)
 };
 
 constexpr int kTierAThreads = 1024;

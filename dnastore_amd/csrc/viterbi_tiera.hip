@@ -131,13 +131,17 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
                    double* __restrict__ arena, double* __restrict__ outLoglike,
                    unsigned long long* __restrict__ roundsTotal) {
   extern __shared__ double lds[];
+  extern __shared__ unsigned ldsU[];
   constexpr int T = DNAS_T, K = DNAS_K, D_ = DNAS_D, lanes = 2, NS = DNAS_NS;   // stored lanes: S, D
   const int tid = threadIdx.x;
   char* const ldsB = reinterpret_cast<char*>(lds);
   double* const X = lds;
   const double* const subL = lds + (kTabBase / 8) + 4;
   const double* const lenL = subL + 16;
-  volatile unsigned* const voteL = reinterpret_cast<volatile unsigned*>(lds + (kTabBase / 8) + 28 + DNAS_T / 64);
+  // the vote words live in the same dynamic LDS block; a second extern array (same base) keeps
+  // the accesses in the LDS address space (a volatile generic pointer would turn them into
+  // flat_* operations that wait on every outstanding global store)
+  unsigned* const voteL = ldsU + 2 * ((kTabBase / 8) + 28 + DNAS_T / 64);
 
   const int read = batchRead[blockIdx.x];
   const unsigned char* seq = bases + readOff[read];
@@ -208,8 +212,8 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
     } else {
       static_for<0, K>([&](auto kc) {
         constexpr int k = kc.value;
-        const int slot = k * T + tid;
-        S[k] = (slot < a.N && (a.local || (META(k) & 0x80000000u))) ? 0.0 : kNegInf;   // viterbi.cpp:75-79; bit31: state 0
+        const unsigned mt = META(k);    // bit29: real state, bit31: reference state 0
+        S[k] = ((mt & 0x20000000u) && (a.local || (mt & 0x80000000u))) ? 0.0 : kNegInf;   // viterbi.cpp:75-79
       });
     }
     __syncthreads();   // every gather of the previous column (and every phase-A push) is done
@@ -258,12 +262,16 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
       double buf[2][kMaxRowVals > 0 ? kMaxRowVals : 1];
       auto issue = [&](auto kc) {
         constexpr int k = kc.value, o = rowOffset(k), b = k & 1;
+#ifdef DNAS_DIAG_NO_LDS_READS   // timing experiment: what do the sweeps cost without their gathers
+        static_for<0, rowEE(k) + 2 * rowEN(k)>([&](auto ec) { buf[b][ec.value] = __uint_as_float(E[o]) > 3.f ? 1.0 : kNegInf; });
+#else
         static_for<0, rowEE(k)>([&](auto ec) { buf[b][ec.value] = ldsRead(ldsB, E[o + ec.value]); });
         static_for<0, rowEN(k)>([&](auto ec) {
           const unsigned addr = E[o + rowEE(k) + ec.value];
           buf[b][rowEE(k) + 2 * ec.value] = ldsRead(ldsB, addr);
           buf[b][rowEE(k) + 2 * ec.value + 1] = ldsRead(ldsB, addr + kCellBytes);
         });
+#endif
       };
       if (tid == 0) voteL[(sweep + 1) % 3] = 0;
       issue(IntC<0>{});
@@ -312,8 +320,14 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
       });
       ++rounds;
       if (__any(changed) && (tid & 63) == 0) voteL[sweep % 3] = 1;
+#ifndef DNAS_DIAG_NO_BARRIER
       __syncthreads();
+#endif
+#ifdef DNAS_DIAG_FIXED_SWEEPS
+      if (sweep + 1 >= DNAS_DIAG_FIXED_SWEEPS) break;
+#else
       if (!voteL[sweep % 3]) break;
+#endif
     }
     STAMP(tB)
 
@@ -356,7 +370,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
               ldsWrite(ldsB, ENT_ADDR(en), kNegInf);
             }
           });
-          if (slot < a.N) {
+          if (meta[k] & 0x20000000u) {
             col[slot] = s;
             col[(size_t)NS + slot] = Dv[k];
           }
@@ -393,8 +407,8 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
   double best = kNegInf;
   static_for<0, K>([&](auto kc) {
     constexpr int k = kc.value;
-    const bool isEnd = (META(k) & 0x40000000u) != 0;
-    if (a.local ? (k * T + tid < a.N) : isEnd) best = dmax(best, S[k]);
+    const unsigned mt = META(k);
+    if (a.local ? (mt & 0x20000000u) != 0 : (mt & 0x40000000u) != 0) best = dmax(best, S[k]);
   });
   for (int off = 32; off > 0; off >>= 1) best = dmax(best, __shfl_down(best, off, 64));
   if ((tid & 63) == 0) red[tid >> 6] = best;

@@ -2,7 +2,7 @@
 import os, sys, time, ctypes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-os.environ["DNAS_TIERA_DEFS"] = "-DDNAS_STAMP"
+os.environ["DNAS_TIERA_DEFS"] = "-DDNAS_STAMP" + "".join("\n" + d for d in sys.argv[2:])
 import numpy as np
 import dnastore_amd as da
 from dnastore_amd import lib as L
