@@ -22,7 +22,9 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
   p.N = N; p.D = D; p.T = T;
   auto no = [&](const std::string& why) { p.ok = false; p.whyNot = why; return p; };
   if (D > 8) return no("more than 8 duplication lanes");
-  const int K = (N + T - 1) / T;
+  // rows come in pairs: a thread's rows 2m and 2m+1 are neighbours in the HBM lattice, so that
+  // the column goes out (and the S history comes back) as 16-byte accesses
+  const int K = 2 * ((N + 2 * T - 1) / (2 * T));
   if (K > kTierAMaxRows) return no("more than " + std::to_string(kTierAMaxRows * T) + " states");
   p.K = K; p.NS = K * T;
 
@@ -60,8 +62,8 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
   const int readDummy = C - 1, writeDummy = C - 2;
   p.C = C;
   p.xDummy = p.NS + 2 * C;           // one extra double behind SN[], always -inf
-  // X | DN | SN | -inf | score[4] sub[16] len[8] | red[T/64] | vote[3]
-  p.ldsBytes = (size_t)(p.NS + 2 * C + 1 + 28 + T / 64 + 2) * sizeof(double);
+  // X | DN | SN | -inf | score[4] sub[16] len[8] | red[T/64] | epoch, idle[T/64] (u32)
+  p.ldsBytes = (size_t)(p.NS + 2 * C + 1 + 28 + T / 64 + (T / 64 + 2) / 2 + 1) * sizeof(double);
   if (p.ldsBytes > kTierALdsLimit) return no("LDS working set " + std::to_string(p.ldsBytes) + " B exceeds one CU");
 
   // pushes, filed under the source state
@@ -107,7 +109,8 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
   for (int pass = 0; pass < 3; ++pass) {
     for (int k = 0; k < K; ++k) {
       const int lo = k * T, hi = std::min(N, (k + 1) * T);
-      std::vector<int> lanesFree(T, 1), pending;
+      if (lo >= hi) continue;             // padding row
+      std::vector<int> lanesFree(T, 1);
       std::vector<int> newLane(hi - lo, -1);
       // exact lane of the primary source first, then same residue, then anything
       for (int i = lo; i < hi; ++i) {
@@ -135,12 +138,16 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
       for (int i = lo; i < hi; ++i) laneOf[order[i]] = newLane[i - lo];
     }
   }
+  // two index spaces: LDS index row*T + lane (consecutive lanes -> consecutive bank pairs), and
+  // the lattice slot (row/2)*2T + 2*lane + (row&1) used in HBM and by the traceback
   p.slotOf.assign(N, -1);
-  p.stateOf.assign(p.NS, -1);
+  p.stateOf.assign(p.NS, -1);       // by LDS index
+  std::vector<int> ldsIdx(N, -1);
   for (int j = 0; j < N; ++j) {
-    const int slot = rowOfState[j] * T + laneOf[j];
-    p.slotOf[j] = slot;
-    p.stateOf[slot] = j;
+    const int row = rowOfState[j], lane = laneOf[j];
+    ldsIdx[j] = row * T + lane;
+    p.stateOf[ldsIdx[j]] = j;
+    p.slotOf[j] = (row >> 1) * 2 * T + 2 * lane + (row & 1);
   }
   // cell numbering: a null pull reads DN/SN[cell(src)]; give the cell the bank pair of its first
   // consumer's lane, buckets balanced so that C does not grow
@@ -212,7 +219,7 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
         for (int e = 0; e < r.e[s]; ++e, ++m, ++epos) {
           unsigned v = (unsigned)p.xDummy * 8u;
           if (e < (int)mine.size()) {
-            v = (unsigned)p.slotOf[mine[e]->src] * 8u;
+            v = (unsigned)ldsIdx[mine[e]->src] * 8u;
             bases |= (unsigned)(mine[e]->base & 3) << (2 * epos);
           }
           p.entTab[(size_t)m * T + t] = v;

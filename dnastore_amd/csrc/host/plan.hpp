@@ -30,7 +30,7 @@ struct TierAPlan {
   std::string defines;            // "-DDNAS_T=.. -DDNAS_K=.. -DDNAS_D=.. -DDNAS_ROWS=.." joined by '\n'
   std::string key;                // cache key of the specialisation
   std::vector<int32_t> slotOf;    // [N]  state -> slot
-  std::vector<int32_t> stateOf;   // [NS] slot -> state or -1
+  std::vector<int32_t> stateOf;   // [NS] LDS index (row*T + lane) -> state or -1
   std::vector<uint32_t> entTab;   // [nEntries][T]
   std::vector<uint32_t> metaTab;  // [K][T]  mdl | ctx<<4 | flags
   std::vector<uint32_t> baseTab;  // [K][T]  emitted base of each emit pull of the row, 2 bits each
@@ -41,7 +41,7 @@ struct TierAPlan {
 };
 
 constexpr int kTierAThreads = 1024;
-constexpr int kTierAMaxRows = 13;
+constexpr int kTierAMaxRows = 14;
 constexpr size_t kTierALdsLimit = 160 * 1024 - 1024;  // leave room for the static reduction buffer
 
 TierAPlan buildTierAPlan(const dnas_flat_model& fm);

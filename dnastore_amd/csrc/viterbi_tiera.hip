@@ -59,6 +59,9 @@ constexpr int maxRowVals() {
 }
 constexpr int kMaxRowVals = maxRowVals();
 
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+static_assert(DNAS_K % 2 == 0, "rows come in pairs");
+
 template <int V> struct IntC { static constexpr int value = V; };
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -78,7 +81,7 @@ struct TierAArgs {
   double score[4];  // score table, score[0] == 0
 };
 
-// LDS map (bytes):  X[NS] | DN[C] | SN[C] | negInf | score[4] | sub[16] | len[8] | red[T/64] | vote[3] (u32)
+// LDS map (bytes):  X[NS] | DN[C] | SN[C] | negInf | score[4] | sub[16] | len[8] | red[T/64] | epoch, idle[T/64] (u32)
 constexpr int kXBytes = DNAS_NS * 8;
 constexpr int kCellBytes = DNAS_C * 8;           // SN[cell] sits kCellBytes behind DN[cell]
 constexpr int kTabBase = kXBytes + 2 * kCellBytes + 8;
@@ -141,7 +144,8 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
   // the vote words live in the same dynamic LDS block; a second extern array (same base) keeps
   // the accesses in the LDS address space (a volatile generic pointer would turn them into
   // flat_* operations that wait on every outstanding global store)
-  unsigned* const voteL = ldsU + 2 * ((kTabBase / 8) + 28 + DNAS_T / 64);
+  unsigned* const epochL = ldsU + 2 * ((kTabBase / 8) + 28 + DNAS_T / 64);   // termination words: epoch, idle[T/64]
+  unsigned* const idleL = epochL + 1;
 
   const int read = batchRead[blockIdx.x];
   const unsigned char* seq = bases + readOff[read];
@@ -167,8 +171,29 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
   if (tid < 4) lds[kTabBase / 8 + tid] = a.score[tid];
   if (tid < 16) lds[kTabBase / 8 + 4 + tid] = a.sub[tid];
   if (tid < 8) lds[kTabBase / 8 + 20 + tid] = a.len[tid];
-  if (tid < 3) voteL[tid] = 0;
+  if (tid < 1 + DNAS_T / 64) epochL[tid] = 0;
   __syncthreads();
+
+  // The S and D lanes of column p leave for HBM from the registers, 16 bytes per lane (rows 2m and
+  // 2m+1 of a thread are lattice neighbours).
+#define STORE_COLUMN(p)                                                                          \
+  {                                                                                              \
+    double* const colp = lat + (size_t)(p) * lanes * NS;                                         \
+    static_for<0, K / 2>([&](auto mc) {                                                          \
+      constexpr int m2 = mc.value;                                                               \
+      if (pairValid & (1u << m2)) {                                                              \
+        dbl2 sv, dv;                                                                             \
+        sv.x = S[2 * m2]; sv.y = S[2 * m2 + 1];                                                  \
+        dv.x = Dv[2 * m2]; dv.y = Dv[2 * m2 + 1];                                                \
+        reinterpret_cast<dbl2*>(colp + (size_t)m2 * 2 * T)[tid] = sv;                            \
+        reinterpret_cast<dbl2*>(colp + (size_t)NS + (size_t)m2 * 2 * T)[tid] = dv;               \
+      }                                                                                          \
+    });                                                                                          \
+  }
+  unsigned pairValid = 0;   // bit m: the lattice pair (rows 2m, 2m+1) of this thread holds a real state
+  static_for<0, K / 2>([&](auto mc) {
+    if ((META(2 * mc.value) | META(2 * mc.value + 1)) & 0x20000000u) pairValid |= 1u << mc.value;
+  });
 
   for (int pos = 0; pos <= L; ++pos) {
     double* const col = lat + (size_t)pos * lanes * NS;
@@ -253,81 +278,100 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
     __syncthreads();
     STAMP(tP)
 
-    // ---- phase B: sweeps to the fixpoint (viterbi.cpp:97-99,110-159).  The LDS reads of row
-    // k+1 are issued before row k is evaluated (software pipeline: the gather latency hides
-    // behind the previous row's arithmetic); one barrier per sweep, the "did anything grow"
-    // vote goes through three rotating LDS words.
-    for (unsigned sweep = 0;; ++sweep) {
-      int changed = 0;
-      double buf[2][kMaxRowVals > 0 ? kMaxRowVals : 1];
-      auto issue = [&](auto kc) {
-        constexpr int k = kc.value, o = rowOffset(k), b = k & 1;
+    // ---- phase B: sweeps to the fixpoint (viterbi.cpp:97-99,110-159), WITHOUT a barrier per
+    // sweep.  Every wave keeps sweeping its own rows (chaotic relaxation: a monotone max-plus
+    // system reaches the same least fixpoint under any schedule) and the work-group agrees on
+    // termination through LDS words:
+    //     epoch    bumped by a wave whose sweep grew a cell
+    //     idle[w]  = e+1 once wave w has finished a sweep that grew nothing and saw epoch == e
+    //              from its first read to its last
+    // When all waves are idle at the same epoch, nothing was written while each of them swept:
+    // every cell is consistent with its inputs, i.e. the fixpoint.  The LDS reads of row k+1 are
+    // issued before row k is evaluated (software pipeline).
+    {
+      constexpr int NW = DNAS_T / 64;
+      const int wv = tid >> 6, ln = tid & 63;
+      for (;;) {
+        asm volatile("" ::: "memory");   // other waves write LDS between sweeps: reload everything
+        const unsigned e0 = __hip_atomic_load(epochL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (ln == 0) __hip_atomic_store(&idleL[wv], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        int changed = 0;
+        double buf[2][kMaxRowVals > 0 ? kMaxRowVals : 1];
+        auto issue = [&](auto kc) {
+          constexpr int k = kc.value, o = rowOffset(k), b = k & 1;
 #ifdef DNAS_DIAG_NO_LDS_READS   // timing experiment: what do the sweeps cost without their gathers
-        static_for<0, rowEE(k) + 2 * rowEN(k)>([&](auto ec) { buf[b][ec.value] = __uint_as_float(E[o]) > 3.f ? 1.0 : kNegInf; });
+          static_for<0, rowEE(k) + 2 * rowEN(k)>([&](auto ec) { buf[b][ec.value] = __uint_as_float(E[o]) > 3.f ? 1.0 : kNegInf; });
 #else
-        static_for<0, rowEE(k)>([&](auto ec) { buf[b][ec.value] = ldsRead(ldsB, E[o + ec.value]); });
-        static_for<0, rowEN(k)>([&](auto ec) {
-          const unsigned addr = E[o + rowEE(k) + ec.value];
-          buf[b][rowEE(k) + 2 * ec.value] = ldsRead(ldsB, addr);
-          buf[b][rowEE(k) + 2 * ec.value + 1] = ldsRead(ldsB, addr + kCellBytes);
-        });
+          static_for<0, rowEE(k)>([&](auto ec) { buf[b][ec.value] = ldsRead(ldsB, E[o + ec.value]); });
+          static_for<0, rowEN(k)>([&](auto ec) {
+            const unsigned addr = E[o + rowEE(k) + ec.value];
+            buf[b][rowEE(k) + 2 * ec.value] = ldsRead(ldsB, addr);
+            buf[b][rowEE(k) + 2 * ec.value + 1] = ldsRead(ldsB, addr + kCellBytes);
+          });
 #endif
-      };
-      if (tid == 0) voteL[(sweep + 1) % 3] = 0;
-      issue(IntC<0>{});
-      static_for<0, K>([&](auto kc) {
-        constexpr int k = kc.value, o = rowOffset(k), b = k & 1;
-        if constexpr (k + 1 < K) issue(IntC<k + 1>{});
-        double s = S[k], d = Dv[k];
-        static_for<0, rowEE(k)>([&](auto ec) {
-          constexpr int cls = emitClass(k, ec.value);
-          double v = buf[b][ec.value];
-          if constexpr (cls != 0) v = v + scoreC[cls];
-          d = dmax(d, v);
-        });
-        static_for<0, rowEN(k)>([&](auto ec) {
-          constexpr int cls = nullClass(k, ec.value);
-          double vd = buf[b][rowEE(k) + 2 * ec.value], vs = buf[b][rowEE(k) + 2 * ec.value + 1];
-          if constexpr (cls != 0) { vd = vd + scoreC[cls]; vs = vs + scoreC[cls]; }
-          d = dmax(d, vd);
-          s = dmax(s, vs);
-        });
-        s = dmax(s, d + a.delEnd);
-        if (s != S[k] || d != Dv[k]) {
-          changed = 1;
-          S[k] = s;
-          Dv[k] = d;
-          const double xv = dmax(d + a.delExtend, s + a.delOpen);
-          X[k * T + tid] = xv;
-          static_for<0, kRows[k].ec>([&](auto ec) {
-            const unsigned en = E[o + rowEE(k) + rowEN(k) + kRows[k].ep + ec.value];
-            if (ENT_HASCELL(en)) {   // a heavy destination's cell also receives pushes: only ever raise it
-              ldsMax(ldsB, ENT_ADDR(en) + kCellBytes, s);
-              ldsMax(ldsB, ENT_ADDR(en), d);
-            }
+        };
+        issue(IntC<0>{});
+        static_for<0, K>([&](auto kc) {
+          constexpr int k = kc.value, o = rowOffset(k), b = k & 1;
+          if constexpr (k + 1 < K) issue(IntC<k + 1>{});
+          double s = S[k], d = Dv[k];
+          static_for<0, rowEE(k)>([&](auto ec) {
+            constexpr int cls = emitClass(k, ec.value);
+            double v = buf[b][ec.value];
+            if constexpr (cls != 0) v = v + scoreC[cls];
+            d = dmax(d, v);
           });
-          static_for<0, kRows[k].ep>([&](auto ec) {
-            const unsigned en = E[o + rowEE(k) + rowEN(k) + ec.value];
-            const double sc = ldsRead(ldsB, kTabBase + ENT_SCOFF(en));
-            if (ENT_FLAG(en)) {
-              ldsMax(ldsB, ENT_ADDR(en), xv + sc);
-            } else {
-              ldsMax(ldsB, ENT_ADDR(en), d + sc);
-              ldsMax(ldsB, ENT_ADDR(en) + kCellBytes, s + sc);
-            }
+          static_for<0, rowEN(k)>([&](auto ec) {
+            constexpr int cls = nullClass(k, ec.value);
+            double vd = buf[b][rowEE(k) + 2 * ec.value], vs = buf[b][rowEE(k) + 2 * ec.value + 1];
+            if constexpr (cls != 0) { vd = vd + scoreC[cls]; vs = vs + scoreC[cls]; }
+            d = dmax(d, vd);
+            s = dmax(s, vs);
           });
+          s = dmax(s, d + a.delEnd);
+          if (s != S[k] || d != Dv[k]) {
+            changed = 1;
+            S[k] = s;
+            Dv[k] = d;
+            const double xv = dmax(d + a.delExtend, s + a.delOpen);
+            X[k * T + tid] = xv;
+            static_for<0, kRows[k].ec>([&](auto ec) {
+              const unsigned en = E[o + rowEE(k) + rowEN(k) + kRows[k].ep + ec.value];
+              if (ENT_HASCELL(en)) {   // a heavy destination's cell also receives pushes: only ever raise it
+                ldsMax(ldsB, ENT_ADDR(en) + kCellBytes, s);
+                ldsMax(ldsB, ENT_ADDR(en), d);
+              }
+            });
+            static_for<0, kRows[k].ep>([&](auto ec) {
+              const unsigned en = E[o + rowEE(k) + rowEN(k) + ec.value];
+              const double sc = ldsRead(ldsB, kTabBase + ENT_SCOFF(en));
+              if (ENT_FLAG(en)) {
+                ldsMax(ldsB, ENT_ADDR(en), xv + sc);
+              } else {
+                ldsMax(ldsB, ENT_ADDR(en), d + sc);
+                ldsMax(ldsB, ENT_ADDR(en) + kCellBytes, s + sc);
+              }
+            });
+          }
+        });
+        ++rounds;
+        if (__any(changed)) {
+          // the data writes above precede the bump (LDS operations of one wave execute in order)
+          if (ln == 0) __hip_atomic_fetch_add(epochL, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          continue;
         }
-      });
-      ++rounds;
-      if (__any(changed) && (tid & 63) == 0) voteL[sweep % 3] = 1;
-#ifndef DNAS_DIAG_NO_BARRIER
-      __syncthreads();
-#endif
-#ifdef DNAS_DIAG_FIXED_SWEEPS
-      if (sweep + 1 >= DNAS_DIAG_FIXED_SWEEPS) break;
-#else
-      if (!voteL[sweep % 3]) break;
-#endif
+        if (__hip_atomic_load(epochL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != e0) continue;
+        if (ln == 0) __hip_atomic_store(&idleL[wv], e0 + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        bool done = false;
+        for (;;) {   // every wave reaches this exit: once all are idle nobody sweeps, so nobody bumps the epoch
+          const unsigned v = ln < NW ? __hip_atomic_load(&idleL[ln], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : e0 + 1u;
+          if (__all(v == e0 + 1u)) { done = true; break; }
+          if (__hip_atomic_load(epochL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != e0) break;   // someone grew a cell: sweep again
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (done) break;
+      }
+      __syncthreads();   // all waves are out of the sweeps before phase C reuses X[]
     }
     STAMP(tB)
 
@@ -343,26 +387,35 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
     // wrote it), a group of rows per memory latency.
     {
       const int xn = pos < L ? seq[pos] : 0;
-      unsigned meta[K];
-      static_for<0, K>([&](auto kc) { meta[kc.value] = META(kc.value); });
       int xh[D_ > 0 ? D_ : 1];   // xh[i] = x_{pos-i}
       static_for<0, D_>([&](auto ic) { xh[ic.value] = pos - ic.value >= 1 ? seq[pos - ic.value - 1] : 0; });
-      constexpr int G = 4;
+      // rows 2m, 2m+1 of a thread are neighbours in the lattice: 16-byte loads and stores
+      constexpr int G = 4;                         // rows per load group (two pairs)
       static_for<0, (K + G - 1) / G>([&](auto gc) {
         constexpr int k0 = gc.value * G, k1 = (k0 + G < K) ? k0 + G : K;
+        unsigned metaG[G];
+        static_for<k0, k1>([&](auto kc) { metaG[kc.value - k0] = META(kc.value); });
         double sh[G][D_ > 1 ? D_ - 1 : 1];
         static_for<1, D_>([&](auto ic) {
           constexpr int i = ic.value;
           if (pos - i >= 1) {
-            static_for<k0, k1>([&](auto kc) { sh[kc.value - k0][i - 1] = (col - (size_t)i * lanes * NS)[kc.value * T + tid]; });
+            static_for<k0 / 2, k1 / 2>([&](auto mc) {
+              constexpr int m2 = mc.value;
+#ifdef DNAS_DIAG_NO_HIST   // timing experiment
+              dbl2 v2; v2.x = S[2 * m2]; v2.y = S[2 * m2 + 1];
+#else
+              const dbl2 v2 = reinterpret_cast<const dbl2*>(col - (size_t)i * lanes * NS + (size_t)m2 * 2 * T)[tid];
+#endif
+              sh[2 * m2 - k0][i - 1] = v2.x;
+              sh[2 * m2 + 1 - k0][i - 1] = v2.y;
+            });
           }
         });
         static_for<k0, k1>([&](auto kc) {
           constexpr int k = kc.value, o = rowOffset(k);
-          const int slot = k * T + tid;
           const double s = S[k];
-          const int mdl = (int)(meta[k] & 15u);
-          X[slot] = s;
+          const int mdl = (int)(metaG[k - k0] & 15u);
+          X[k * T + tid] = s;
           static_for<0, kRows[k].ec>([&](auto ec) {
             const unsigned en = E[o + rowEE(k) + rowEN(k) + kRows[k].ep + ec.value];
             if (ENT_HASCELL(en) && ENT_FLAG(en)) {
@@ -370,28 +423,45 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
               ldsWrite(ldsB, ENT_ADDR(en), kNegInf);
             }
           });
-          if (meta[k] & 0x20000000u) {
-            col[slot] = s;
-            col[(size_t)NS + slot] = Dv[k];
-          }
-          // T1(pos): chain from the deepest element (i = D-1) to i = 0
+          // T1(pos): chain from the deepest element (i = D-1) to i = 0.  Nearly every state has a
+          // full context (mdl == D) and nearly every column a full history: that case is straight
+          // line code, chosen per wave.
+          const bool valid = (metaG[k - k0] & 0x20000000u) != 0;
           double v = kNegInf;
-          static_for<0, D_>([&](auto jc) {
-            constexpr int i = D_ - 1 - jc.value;           // lane q = i at column p = pos - i
-            if (i < mdl && pos - i >= 1) {
-              double sp = s;
-              if constexpr (i > 0) sp = sh[k - k0][i - 1];
-              const double base = (sp + a.tanDup) + lenL[i];
-              if (i + 1 < mdl && pos - i - 1 >= 1)
-                v = dmax(v + subL[((meta[k] >> (4 + 2 * (i + 1))) & 3u) * 4 + xh[i]], base);
-              else
-                v = base;
+          if (pos >= D_ && __all(mdl == D_ || !valid)) {
+            if constexpr (D_ > 0) {
+              double sd = s;
+              if constexpr (D_ > 1) sd = sh[k - k0][D_ - 2];
+              v = (sd + a.tanDup) + a.len[D_ - 1];
+              static_for<1, D_>([&](auto jc) {
+                constexpr int i = D_ - 1 - jc.value;         // i = D-2 .. 0
+                double sp = s;
+                if constexpr (i > 0) sp = sh[k - k0][i - 1];
+                v = dmax(v + ldsRead(ldsB, kTabBase + 32 + ((metaG[k - k0] >> (4 + 2 * (i + 1))) & 3u) * 32 + xh[i] * 8),
+                         (sp + a.tanDup) + a.len[i]);
+              });
             }
-          });
+          } else {
+            static_for<0, D_>([&](auto jc) {
+              constexpr int i = D_ - 1 - jc.value;           // lane q = i at column p = pos - i
+              if (i < mdl && pos - i >= 1) {
+                double sp = s;
+                if constexpr (i > 0) sp = sh[k - k0][i - 1];
+                const double base = (sp + a.tanDup) + a.len[i];
+                if (i + 1 < mdl && pos - i - 1 >= 1)
+                  v = dmax(v + subL[((metaG[k - k0] >> (4 + 2 * (i + 1))) & 3u) * 4 + xh[i]], base);
+                else
+                  v = base;
+              }
+            });
+          }
           // next column: S >= T1(pos) + sub[ctx1][x_{pos+1}]   (viterbi.cpp:101-103)
-          tc[k] = (mdl > 0) ? v + subL[((meta[k] >> 4) & 3u) * 4 + xn] : kNegInf;
+          tc[k] = (valid && mdl > 0) ? v + subL[((metaG[k - k0] >> 4) & 3u) * 4 + xn] : kNegInf;
         });
       });
+      // all of the column's stores go out last: a wave's memory operations return in order, so a
+      // store issued between two groups would sit in front of the next group's history loads
+      STORE_COLUMN(pos)
     }
     __syncthreads();   // X[] now holds S(pos) for everyone
     STAMP(tC)
@@ -423,7 +493,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
   if (a.local) {
     static_for<0, K>([&](auto kc) {
       constexpr int k = kc.value;
-      if (META(k) & 0x40000000u) lastS[k * T + tid] = red[0];
+      if (META(k) & 0x40000000u) lastS[(k >> 1) * 2 * T + 2 * tid + (k & 1)] = red[0];
     });
   }
 }
