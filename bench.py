@@ -178,7 +178,8 @@ def main():
                        "reads_per_gpu": args.reads, "total_nt": int(total_nt), "parallelism": "read-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "viterbi_fill_kernel", "avg_launch_ms": fill_ms / max(launches, 1),
+                         "kernel": "viterbi_fill_tiera" if dec.tier.startswith("tier A") else "viterbi_fill_kernel",
+                         "tier": dec.tier[:6], "avg_launch_ms": fill_ms / max(launches, 1),
                          "algorithmic_bytes_per_launch": stats["lattice_bytes"] / max(stats["fill_launches"], 1),
                          "rounds_per_column": stats["rounds"] / max(stats["columns"], 1),
                          "traceback_ms_per_step": tb_ms / args.steps},

@@ -237,3 +237,80 @@ def decode_fastseqs(filename, machine, params, device=0):
            for i in range(L.dnas_decoded_count(h))]
     L.dnas_decoded_free(h)
     return out
+
+
+class StockholmDB:
+    """readStockholmDatabase (stockholm.cpp:154-167) of two-row alignments, flattened for the E-step."""
+
+    def __init__(self, path):
+        self._h = ctypes.c_void_p()
+        _l.check(_l.lib().dnas_stockholm_read(str(path).encode(), ctypes.byref(self._h)))
+        self.view = _l.lib().dnas_pairs_get(self._h).contents
+        self.n = self.view.n_pairs
+
+    def arrays(self):
+        """numpy copies: ins, in_off, outs, out_off, cm_in, cm_in_off, cm_out, cm_out_off."""
+        v, n = self.view, self.n
+
+        def arr(ptr, count, dt):
+            if count == 0:
+                return np.zeros(0, dt)
+            return np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(count,)).copy()
+        in_off = arr(v.in_off, n + 1, np.int64)
+        out_off = arr(v.out_off, n + 1, np.int64)
+        ci_off = arr(v.cm_in_off, n + 1, np.int64)
+        co_off = arr(v.cm_out_off, n + 1, np.int64)
+        return dict(ins=arr(v.in_seqs, int(in_off[-1]), np.int8), in_off=in_off, outs=arr(v.out_seqs, int(out_off[-1]), np.int8),
+                    out_off=out_off, cm_in=arr(v.cm_in, int(ci_off[-1]), np.int32), cm_in_off=ci_off,
+                    cm_out=arr(v.cm_out, int(co_off[-1]), np.int32), cm_out_off=co_off, n=n)
+
+    def __del__(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _l.lib().dnas_pairs_free(self._h)
+            self._h = ctypes.c_void_p()
+
+
+def _pair_ptrs(pk):
+    keys = ("ins", "in_off", "outs", "out_off", "cm_in", "cm_in_off", "cm_out", "cm_out_off")
+    dts = (np.int8, np.int64, np.int8, np.int64, np.int32, np.int64, np.int32, np.int64)
+    keep = [np.ascontiguousarray(pk[k], dtype=d) if len(pk[k]) else np.zeros(1, d) for k, d in zip(keys, dts)]
+    return keep, [a.ctypes.data for a in keep]
+
+
+def expectedCounts(params, pairs, strict=False, device=0):
+    """expectedCounts(params, db, ll, strict) (fwdback.cpp:190-209) on the GPU.
+    pairs: StockholmDB or a dict of packed arrays (ins, in_off, outs, out_off, cm_in, cm_in_off, cm_out, cm_out_off, n).
+    -> (counts float64[21+P], ll, per-pair ll float64[n])."""
+    pk = pairs.arrays() if isinstance(pairs, StockholmDB) else pairs
+    keep, ptrs = _pair_ptrs(pk)
+    n = int(pk["n"])
+    counts = np.zeros(21 + params.c.n_len)
+    ll = ctypes.c_double()
+    per = np.zeros(max(n, 1))
+    _l.check(_l.lib().dnas_fwdback_estep(ctypes.byref(params.c), int(bool(strict)), n, *ptrs, int(device), counts.ctypes.data,
+                                         ctypes.addressof(ll), per.ctypes.data))
+    return counts, ll.value, per[:n]
+
+
+def baumWelchParams(init, pairs, strict=False, device=0):
+    """baumWelchParams(init, Laplace prior, db, strict) (fwdback.cpp:211-230) -> (fitted MutatorParams, iterations)."""
+    pk = pairs.arrays() if isinstance(pairs, StockholmDB) else pairs
+    keep, ptrs = _pair_ptrs(pk)
+    out = _l.MutatorParamsC()
+    it = ctypes.c_int32()
+    _l.check(_l.lib().dnas_baum_welch(ctypes.byref(init.c), int(bool(strict)), int(pk["n"]), *ptrs, int(device), ctypes.byref(out),
+                                      ctypes.addressof(it)))
+    return MutatorParams(out), it.value
+
+
+def paramsJSON(params):
+    buf = ctypes.create_string_buffer(4096)
+    _l.check(_l.lib().dnas_mutator_params_json(ctypes.byref(params.c), buf, 4096))
+    return buf.value.decode()
+
+
+def countsJSON(counts, n_len):
+    c = np.ascontiguousarray(counts, dtype=np.float64)
+    buf = ctypes.create_string_buffer(8192)
+    _l.check(_l.lib().dnas_mutator_counts_json(c.ctypes.data, int(n_len), buf, 8192))
+    return buf.value.decode()

@@ -13,10 +13,12 @@
 #include "host/fastseq.hpp"
 #include "host/machine.hpp"
 #include "host/model.hpp"
+#include "host/stockholm.hpp"
 
 struct dnas_machine { dnas::Machine machine; };
 struct dnas_flat { dnas::FlatModel flat; };
 struct dnas_fastseqs { std::vector<dnas::FastSeq> seqs; };
+struct dnas_pairs { dnas::AlignmentPairs db; dnas_pairs_view view; };
 struct dnas_decoded {
   std::vector<dnas::FastSeq> seqs;
   std::vector<double> loglike;
@@ -165,6 +167,73 @@ int64_t dnas_fastseqs_count(const dnas_fastseqs* f) { return f ? (int64_t)f->seq
 const char* dnas_fastseqs_name(const dnas_fastseqs* f, int64_t i) { return f->seqs[(size_t)i].name.c_str(); }
 const char* dnas_fastseqs_seq(const dnas_fastseqs* f, int64_t i) { return f->seqs[(size_t)i].seq.c_str(); }
 void dnas_fastseqs_free(dnas_fastseqs* f) { delete f; }
+
+int dnas_stockholm_read(const char* path, dnas_pairs** out) {
+  if (!path || !out) return dnas::fail(DNAS_E_INVALID, "null argument");
+  *out = nullptr;
+  return guarded([&] {
+    dnas_pairs* p = new dnas_pairs{dnas::readStockholmPairs(path), {}};
+    const dnas::AlignmentPairs& d = p->db;
+    p->view = dnas_pairs_view{d.n, d.inSeqs.data(), d.inOff.data(), d.outSeqs.data(), d.outOff.data(),
+                              d.cmIn.data(), d.cmInOff.data(), d.cmOut.data(), d.cmOutOff.data()};
+    *out = p;
+    return DNAS_OK;
+  });
+}
+const dnas_pairs_view* dnas_pairs_get(const dnas_pairs* p) { return p ? &p->view : nullptr; }
+void dnas_pairs_free(dnas_pairs* p) { delete p; }
+
+// MutatorParams::writeJSON / MutatorCounts::writeJSON (mutator.cpp:6-16,108-124): the text the
+// reference prints for --fit-error / --error-counts, default 6-digit ostream formatting.
+int dnas_mutator_params_json(const dnas_mutator_params* p, char* buf, size_t cap) {
+  if (!p || !buf || !cap) return dnas::fail(DNAS_E_INVALID, "null argument");
+  return guarded([&] {
+    const std::string s = dnas::MutatorParams::fromC(*p).toJSON();
+    if (s.size() + 1 > cap) return dnas::fail(DNAS_E_INVALID, "buffer too small");
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return DNAS_OK;
+  });
+}
+int dnas_mutator_counts_json(const double* counts, int32_t n_len, char* buf, size_t cap) {
+  if (!counts || !buf || !cap || n_len < 0) return dnas::fail(DNAS_E_INVALID, "bad argument");
+  return guarded([&] {
+    auto trans = [](int i, int j) { return i != j && (i & 1) == (j & 1); };
+    double nm = 0, ni = 0, nv = 0;
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) {
+        const double c = counts[5 + i * 4 + j];
+        if (i == j) nm += c; else if (trans(i, j)) ni += c; else nv += c;
+      }
+    // nMatch / nTransition / nTransversion are summed in the reference's loop order (mutator.cpp:180-196)
+    nm = 0; for (int i = 0; i < 4; ++i) nm += counts[5 + i * 5];
+    ni = 0; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) if (trans(i, j)) ni += counts[5 + i * 4 + j];
+    nv = 0; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) if (i != j && !trans(i, j)) nv += counts[5 + i * 4 + j];
+    std::ostringstream o;
+    o << "{\n";
+    o << " \"nDelOpen\": " << counts[0] << ",\n";
+    o << " \"nTanDup\": " << counts[1] << ",\n";
+    o << " \"nNoGap\": " << counts[2] << ",\n";
+    o << " \"nDelExtend\": " << counts[3] << ",\n";
+    o << " \"nDelEnd\": " << counts[4] << ",\n";
+    o << " \"nLen\": [ ";
+    for (int k = 0; k < n_len; ++k) o << (k ? ", " : "") << counts[21 + k];
+    o << " ],\n \"nSub\": [ ";
+    for (int i = 0; i < 4; ++i) {
+      o << (i ? ", " : "") << "[";
+      for (int j = 0; j < 4; ++j) o << (j ? "," : "") << counts[5 + i * 4 + j];
+      o << "]";
+    }
+    o << " ],\n";
+    o << " \"nMatch\": " << nm << ",\n";
+    o << " \"nTransition\": " << ni << ",\n";
+    o << " \"nTransversion\": " << nv << "\n";
+    o << "}\n";
+    const std::string s = o.str();
+    if (s.size() + 1 > cap) return dnas::fail(DNAS_E_INVALID, "buffer too small");
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return DNAS_OK;
+  });
+}
 
 // decodeFastSeqs (viterbi.cpp:306-320): read the FASTA, build the input model once,
 // decode every read on the GPU, keep names, drop comments.

@@ -46,6 +46,12 @@ class FlatModelC(ctypes.Structure):
                 ("len", _F64P), ("alphabet", ctypes.c_char * 64), ("sym_logp", ctypes.c_double * 128)]
 
 
+class PairsViewC(ctypes.Structure):
+    _fields_ = [("n_pairs", ctypes.c_int64), ("in_seqs", ctypes.c_void_p), ("in_off", ctypes.c_void_p),
+                ("out_seqs", ctypes.c_void_p), ("out_off", ctypes.c_void_p), ("cm_in", ctypes.c_void_p),
+                ("cm_in_off", ctypes.c_void_p), ("cm_out", ctypes.c_void_p), ("cm_out_off", ctypes.c_void_p)]
+
+
 class BatchStatsC(ctypes.Structure):
     _fields_ = [("fill_ms", ctypes.c_double), ("traceback_ms", ctypes.c_double), ("fill_launches", ctypes.c_int64),
                 ("columns", ctypes.c_int64), ("lattice_bytes", ctypes.c_int64), ("rounds", ctypes.c_int64)]
@@ -94,6 +100,13 @@ def lib():
         "dnas_tiera_precompile": (ctypes.c_int, [P(FlatModelC), ctypes.c_char_p, sz]),
         "dnas_model_last_stats": (ctypes.c_int, [vp, P(BatchStatsC)]),
         "dnas_model_read_lattice": (ctypes.c_int, [vp, i64, i64, vp]),
+        "dnas_fwdback_estep": (ctypes.c_int, [P(MutatorParamsC), ctypes.c_int, i64] + [vp] * 8 + [ctypes.c_int, vp, vp, vp]),
+        "dnas_baum_welch": (ctypes.c_int, [P(MutatorParamsC), ctypes.c_int, i64] + [vp] * 8 + [ctypes.c_int, P(MutatorParamsC), vp]),
+        "dnas_stockholm_read": (ctypes.c_int, [cp, P(vp)]),
+        "dnas_pairs_get": (P(PairsViewC), [vp]),
+        "dnas_pairs_free": (None, [vp]),
+        "dnas_mutator_params_json": (ctypes.c_int, [P(MutatorParamsC), ctypes.c_char_p, sz]),
+        "dnas_mutator_counts_json": (ctypes.c_int, [vp, ctypes.c_int32, ctypes.c_char_p, sz]),
         "dnas_decode_fastseqs": (ctypes.c_int, [cp, vp, P(MutatorParamsC), ctypes.c_int, P(vp)]),
         "dnas_decoded_count": (i64, [vp]),
         "dnas_decoded_name": (cp, [vp, i64]),

@@ -165,6 +165,52 @@ int dnas_model_last_stats(const dnas_model *model, dnas_batch_stats *out);
  * layout [pos][lane][n_states], lanes S, D, T1..TD. */
 int dnas_model_read_lattice(dnas_model *model, int64_t slot, int64_t len, double *out);
 
+/* ---- forward-backward path ------------------------------------------------------------ */
+
+/*
+ * expectedCounts(params, db, ll, strict) (reference src/fwdback.cpp:190-209): the E-step of the
+ * mutator pair-HMM over a database of (original, read) alignment pairs, one GPU thread per pair.
+ * Pairs are concatenated: pair i is in_seqs[in_off[i]..in_off[i+1]) / out_seqs[...] (bases 0..3)
+ * with the guide alignment given per sequence position as the cumulative match count at that
+ * position's alignment column (GuideAlignmentEnvelope, alignpath.h:35-54):
+ *   cm_in[cm_in_off[i] + ip],  ip = 0..inLen;   cm_out[cm_out_off[i] + op],  op = 0..outLen.
+ * out_counts[21 + n_len]: nDelOpen, nTanDup, nNoGap, nDelExtend, nDelEnd, nSub[4][4], nLen[]
+ * (MutatorCounts, mutator.h:43-50); *out_ll = sum of forward log-likelihoods; out_pair_ll
+ * (optional, n_pairs) the per-pair values.  Host pointers.
+ */
+int dnas_fwdback_estep(const dnas_mutator_params *params, int strict, int64_t n_pairs, const int8_t *in_seqs,
+                       const int64_t *in_off, const int8_t *out_seqs, const int64_t *out_off, const int32_t *cm_in,
+                       const int64_t *cm_in_off, const int32_t *cm_out, const int64_t *cm_out_off, int device_id,
+                       double *out_counts, double *out_ll, double *out_pair_ll);
+
+/* baumWelchParams(init, Laplace prior, db, strict) (fwdback.cpp:211-230, dnastore.cpp:135-140):
+ * EM on the host around the GPU E-step; at most 100 iterations, stops when the relative gain
+ * of log(likelihood * prior) drops below 1e-3. */
+int dnas_baum_welch(const dnas_mutator_params *init, int strict, int64_t n_pairs, const int8_t *in_seqs,
+                    const int64_t *in_off, const int8_t *out_seqs, const int64_t *out_off, const int32_t *cm_in,
+                    const int64_t *cm_in_off, const int32_t *cm_out, const int64_t *cm_out_off, int device_id,
+                    dnas_mutator_params *out, int32_t *out_iterations);
+
+/* Stockholm database of two-row (original, read) alignments, readStockholmDatabase + Alignment +
+ * GuideAlignmentEnvelope (stockholm.cpp:154-167, alignpath.cpp:189-204,237-265), flattened into the
+ * arrays dnas_fwdback_estep takes. */
+typedef struct dnas_pairs dnas_pairs;
+typedef struct dnas_pairs_view {
+  int64_t n_pairs;
+  const int8_t *in_seqs;  const int64_t *in_off;
+  const int8_t *out_seqs; const int64_t *out_off;
+  const int32_t *cm_in;   const int64_t *cm_in_off;
+  const int32_t *cm_out;  const int64_t *cm_out_off;
+} dnas_pairs_view;
+int dnas_stockholm_read(const char *path, dnas_pairs **out);
+const dnas_pairs_view *dnas_pairs_get(const dnas_pairs *p);
+void dnas_pairs_free(dnas_pairs *p);
+
+/* The JSON the reference prints for --fit-error (MutatorParams::writeJSON, mutator.cpp:6-16) and
+ * --error-counts (MutatorCounts::writeJSON, mutator.cpp:108-124), NUL-terminated into buf. */
+int dnas_mutator_params_json(const dnas_mutator_params *p, char *buf, size_t cap);
+int dnas_mutator_counts_json(const double *counts, int32_t n_len, char *buf, size_t cap);
+
 /* ---- convenience: the whole reference call ------------------------------------------ */
 
 typedef struct dnas_decoded dnas_decoded; /* vguard<FastSeq> result of decodeFastSeqs */

@@ -276,3 +276,127 @@ def read_fasta(path):
         if name is not None:
             recs.append((name, "".join(chunks)))
     return recs
+
+
+# ----------------------------------------------------------------------------- Stockholm / forward-backward
+def read_stockholm(path):
+    """readStockholmDatabase (stockholm.cpp:30-68,154-167): list of alignments, each [(name, gapped row)]."""
+    db, rows, order = [], {}, []
+    with open(path) as f:
+        for line in f:
+            s = line.strip()
+            if not s:
+                continue
+            if s.startswith("//"):
+                if order:
+                    db.append([(n, rows[n]) for n in order])
+                rows, order = {}, []
+                continue
+            if s.startswith("#"):
+                continue
+            parts = s.split()
+            if len(parts) == 2:
+                if parts[0] not in rows:
+                    order.append(parts[0])
+                    rows[parts[0]] = ""
+                rows[parts[0]] += parts[1]
+    if order:
+        db.append([(n, rows[n]) for n in order])
+    return db
+
+
+def alignment_pair(rows):
+    """2-row alignment -> (in tokens, out tokens, cmIn, cmOut) as GuideAlignmentEnvelope sees it
+    (alignpath.cpp:189-204,237-265): cm*[pos] = cumulative matches at the alignment column of `pos`."""
+    assert len(rows) == 2, "Training mutator model requires a 2-row alignment"   # fwdback.cpp:25
+    g1, g2 = rows[0][1], rows[1][1]
+    assert len(g1) == len(g2)
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    is_gap = lambda c: c in "-."
+    cum, matches = [0], 0
+    p1, p2 = [0], [0]
+    for col, (a, b) in enumerate(zip(g1, g2)):
+        if not is_gap(a):
+            p1.append(col + 1)
+        if not is_gap(b):
+            p2.append(col + 1)
+        if not is_gap(a) and not is_gap(b):
+            matches += 1
+        cum.append(matches)
+    ins = np.array([code[c.upper()] for c in g1 if not is_gap(c)], dtype=np.int8)
+    outs = np.array([code[c.upper()] for c in g2 if not is_gap(c)], dtype=np.int8)
+    return ins, outs, np.array([cum[c] for c in p1], dtype=np.int32), np.array([cum[c] for c in p2], dtype=np.int32)
+
+
+def pack_pairs(pairs):
+    """[(ins, outs, cmIn, cmOut)] -> concatenated arrays + offsets (what orc_expected_counts / the C ABI take)."""
+    def cat(idx, dt):
+        arrs = [p[idx] for p in pairs]
+        off = np.zeros(len(arrs) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(a) for a in arrs])
+        data = np.concatenate(arrs).astype(dt) if arrs and off[-1] else np.zeros(1, dt)
+        return data, off
+    ins, in_off = cat(0, np.int8)
+    outs, out_off = cat(1, np.int8)
+    cmi, cmi_off = cat(2, np.int32)
+    cmo, cmo_off = cat(3, np.int32)
+    return dict(ins=ins, in_off=in_off, outs=outs, out_off=out_off, cm_in=cmi, cm_in_off=cmi_off, cm_out=cmo,
+                cm_out_off=cmo_off, n=len(pairs))
+
+
+def _fb_args(pk):
+    i64 = ctypes.c_int64
+    return [_ptr(pk["ins"], ctypes.c_int8), _ptr(pk["in_off"], i64), _ptr(pk["outs"], ctypes.c_int8), _ptr(pk["out_off"], i64),
+            _ptr(pk["cm_in"], ctypes.c_int), _ptr(pk["cm_in_off"], i64), _ptr(pk["cm_out"], ctypes.c_int), _ptr(pk["cm_out_off"], i64)]
+
+
+def expected_counts(params, pairs, strict=False):
+    """expectedCounts (fwdback.cpp:190-209) -> (counts float64[21+P], total ll, per-pair ll)."""
+    L = lib()
+    L.orc_expected_counts.restype = ctypes.c_double
+    pk = pack_pairs(pairs)
+    cp = _cparams(params)
+    counts = np.zeros(21 + len(params.pLen))
+    per = np.zeros(max(pk["n"], 1))
+    ll = L.orc_expected_counts(ctypes.byref(cp), ctypes.c_int(int(strict)), ctypes.c_int(pk["n"]), *_fb_args(pk),
+                               _ptr(counts, ctypes.c_double), _ptr(per, ctypes.c_double))
+    return counts, ll, per[:pk["n"]]
+
+
+def baum_welch(params, pairs, strict=False):
+    """baumWelchParams with the Laplace prior (fwdback.cpp:211-230, dnastore.cpp:137-138) -> fitted MutatorParams."""
+    L = lib()
+    pk = pack_pairs(pairs)
+    p5 = np.array([params.pDelOpen, params.pDelExtend, params.pTanDup, params.pTransition, params.pTransversion])
+    plen = np.array(params.pLen, dtype=np.float64)
+    L.orc_baum_welch(_ptr(p5, ctypes.c_double), ctypes.c_int(len(plen)), ctypes.c_int(int(params.local)),
+                     ctypes.c_int(int(strict)), ctypes.c_int(pk["n"]), *_fb_args(pk), _ptr(plen, ctypes.c_double))
+    return MutatorParams(p5[0], p5[1], p5[2], p5[3], p5[4], list(plen), params.local)
+
+
+def _g(x):
+    return "%g" % x          # default ostream formatting: 6 significant digits
+
+
+def counts_json(counts, P):
+    """MutatorCounts::writeJSON (mutator.cpp:108-124), byte for byte."""
+    sub = counts[5:21].reshape(4, 4)
+    trans = lambda i, j: i != j and (i & 1) == (j & 1)
+    n_match = sum(sub[i][i] for i in range(4))
+    n_ti = sum(sub[i][j] for i in range(4) for j in range(4) if trans(i, j))
+    n_tv = sum(sub[i][j] for i in range(4) for j in range(4) if i != j and not trans(i, j))
+    s = "{\n"
+    s += ' "nDelOpen": %s,\n "nTanDup": %s,\n "nNoGap": %s,\n "nDelExtend": %s,\n "nDelEnd": %s,\n' % tuple(
+        _g(counts[i]) for i in (0, 1, 2, 3, 4))
+    s += ' "nLen": [ %s ],\n' % ", ".join(_g(x) for x in counts[21:21 + P])
+    s += ' "nSub": [ %s ],\n' % ", ".join("[" + ",".join(_g(x) for x in row) + "]" for row in sub)
+    s += ' "nMatch": %s,\n "nTransition": %s,\n "nTransversion": %s\n}\n' % (_g(n_match), _g(n_ti), _g(n_tv))
+    return s
+
+
+def params_json(p):
+    """MutatorParams::writeJSON (mutator.cpp:6-16), byte for byte."""
+    return ("{\n \"pDelOpen\": %s,\n \"pDelExtend\": %s,\n \"pTanDup\": %s,\n \"pTransition\": %s,\n \"pTransversion\": %s,\n"
+            " \"pLen\": [ %s ],\n \"local\": %s\n}\n") % (_g(p.pDelOpen), _g(p.pDelExtend), _g(p.pTanDup), _g(p.pTransition),
+                                                        _g(p.pTransversion), ", ".join(_g(x) for x in p.pLen),
+                                                        "true" if p.local else "false")

@@ -86,3 +86,26 @@ def synthetic_reads(machine, n, nbytes, seed, sub=0.01, dele=0.0, dup=0.0):
         payload = bytes(rng.randrange(256) for _ in range(nbytes))
         reads.append(mutate(encode(machine, bytes_to_symbols(payload)), rng, sub, dele, dup))
     return reads
+
+
+def synthetic_alignment(rng, length, sub=0.02, dele=0.01, dup=0.01):
+    """A random (original, read) pair with its true alignment as two gapped rows (the guide
+    the reference's --error-counts / --fit-error take): tandem duplications of length 1-3,
+    deletions, substitutions."""
+    src = "".join(rng.choice("ACGT") for _ in range(length))
+    r1, r2 = [], []
+    i = 0
+    while i < len(src):
+        r = rng.random()
+        if r < dele:
+            r1.append(src[i]); r2.append("-"); i += 1
+            continue
+        c = src[i]
+        if rng.random() < sub:
+            c = rng.choice([b for b in "ACGT" if b != c])
+        r1.append(src[i]); r2.append(c); i += 1
+        if r < dele + dup and i >= 3:
+            k = rng.randint(1, 3)
+            for b in src[i - k:i]:
+                r1.append("-"); r2.append(b)
+    return [("in", "".join(r1)), ("out", "".join(r2))]

@@ -1,0 +1,82 @@
+"""GPU parity tests of the forward-backward E-step / Baum-Welch path (through the C ABI) against the
+CPU oracle and the reference's five golden files (reference Makefile:156-163).
+
+Per-pair log-likelihoods are bit-exact.  Expected counts are sums of exp() terms: the kernel adds a
+pair's terms in reverse cell order and the database in a tree, the reference serially, and exp() comes
+from different math libraries, so counts are held to 1e-9 relative -- and to the
+reference's printed 6 significant digits exactly."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+COUNT_FLAGS = dict(sub=1e-9, dup=1e-9, del_open=1e-9, length=6)      # testcount, Makefile:156-159
+
+
+@pytest.fixture(scope="module")
+def da():
+    import dnastore_amd
+    return dnastore_amd
+
+
+def _close(a, b):
+    return np.allclose(a, b, rtol=1e-9, atol=1e-300)
+
+
+@pytest.mark.parametrize("stk,gold", [("dup.stk", "dup.counts.json"), ("dup.sub.stk", "dup.sub.counts.json"),
+                                      ("dup.sub.misaligned.stk", "dup.sub.counts.misaligned.json")])
+def test_error_counts_goldens(da, oracle_mod, ref_data, stk, gold):
+    O = oracle_mod
+    params = da.MutatorParams.fromFlags(**COUNT_FLAGS)
+    counts, ll, per = da.expectedCounts(params, da.StockholmDB(os.path.join(ref_data, stk)))
+    assert da.countsJSON(counts, 3) == open(os.path.join(ref_data, gold)).read()          # reference golden, byte for byte
+    oc, oll, oper = O.expected_counts(O.MutatorParams.from_cli(**COUNT_FLAGS),
+                                      [O.alignment_pair(r) for r in O.read_stockholm(os.path.join(ref_data, stk))])
+    assert list(per) == list(oper) and ll == oll                                            # fp64-exact log-likelihoods
+    assert _close(counts, oc)
+
+
+@pytest.mark.parametrize("stk,gold", [("tiny.stk", "tiny.params.json"), ("test.stk", "test.params.json")])
+def test_fit_error_goldens(da, ref_data, stk, gold):
+    fit, iters = da.baumWelchParams(da.MutatorParams.fromFlags(), da.StockholmDB(os.path.join(ref_data, stk)), strict=True)
+    assert da.paramsJSON(fit) == open(os.path.join(ref_data, gold)).read()                 # testfit, Makefile:161-163
+    assert 1 <= iters <= 100
+
+
+@pytest.mark.parametrize("flags,strict", [(dict(), False), (dict(), True), (dict(length=6, sub=.05, dup=.02, del_open=.02), False)])
+def test_synthetic_database(da, oracle_mod, flags, strict):
+    from synth import synthetic_alignment
+    O = oracle_mod
+    rng = random.Random(11)
+    rows = [synthetic_alignment(rng, rng.choice([1, 5, 40, 97, 256])) for _ in range(150)]
+    pairs = [O.alignment_pair(r) for r in rows]
+    pk = O.pack_pairs(pairs)
+    counts, ll, per = da.expectedCounts(da.MutatorParams.fromFlags(**flags), pk, strict=strict)
+    oc, oll, oper = O.expected_counts(O.MutatorParams.from_cli(**flags), pairs, strict=strict)
+    assert np.array_equal(per, oper)               # bit-exact per pair (incl. -inf for pairs the band cannot explain)
+    assert _close(counts, oc)
+    assert ll == pytest.approx(oll, rel=1e-12) or (np.isinf(ll) and ll == oll)
+
+
+def test_baum_welch_matches_oracle(da, oracle_mod):
+    from synth import synthetic_alignment
+    O = oracle_mod
+    rng = random.Random(3)
+    pairs = [O.alignment_pair(synthetic_alignment(rng, 120, sub=.03, dele=.02, dup=.02)) for _ in range(40)]
+    fit, iters = da.baumWelchParams(da.MutatorParams.fromFlags(), O.pack_pairs(pairs))
+    ofit = O.baum_welch(O.MutatorParams.from_cli(), pairs)
+    got = [fit.c.p_del_open, fit.c.p_del_extend, fit.c.p_tan_dup, fit.c.p_transition, fit.c.p_transversion]
+    want = [ofit.pDelOpen, ofit.pDelExtend, ofit.pTanDup, ofit.pTransition, ofit.pTransversion]
+    assert np.allclose(got, want, rtol=1e-9)
+    assert fit.pLen == ofit.pLen and fit.local == ofit.local
+
+
+def test_empty_database(da):
+    counts, ll, per = da.expectedCounts(da.MutatorParams.fromFlags(), dict(
+        ins=np.zeros(0, np.int8), in_off=np.zeros(1, np.int64), outs=np.zeros(0, np.int8), out_off=np.zeros(1, np.int64),
+        cm_in=np.zeros(0, np.int32), cm_in_off=np.zeros(1, np.int64), cm_out=np.zeros(0, np.int32),
+        cm_out_off=np.zeros(1, np.int64), n=0))
+    assert not counts.any() and ll == 0 and len(per) == 0

@@ -79,3 +79,38 @@ def test_lowercase_reads(oracle_mod, ref_data):
     v = O.ViterbiOracle(O.Machine.from_file(os.path.join(ref_data, "l4c4.json")), O.MutatorParams.from_cli())
     seq = O.read_fasta(os.path.join(ref_data, "hello.fa"))[0][1]
     assert v.decode(seq.lower()) == v.decode(seq)
+
+
+# ---------------------------------------------------------------- forward-backward (reference Makefile:156-163)
+@pytest.mark.parametrize("stk,gold,ll", [("dup.stk", "dup.counts.json", 22.539541340221977),
+                                         ("dup.sub.stk", "dup.sub.counts.json", 2.0692720187364166),
+                                         ("dup.sub.misaligned.stk", "dup.sub.counts.misaligned.json", 2.0692720187364166)])
+def test_error_counts_goldens(oracle_mod, ref_data, stk, gold, ll):
+    O = oracle_mod
+    p = O.MutatorParams.from_cli(sub=1e-9, dup=1e-9, del_open=1e-9, length=6)
+    pairs = [O.alignment_pair(r) for r in O.read_stockholm(os.path.join(ref_data, stk))]
+    counts, got_ll, per = O.expected_counts(p, pairs)
+    assert O.counts_json(counts, 3) == open(os.path.join(ref_data, gold)).read()     # testexpect.pl diff
+    assert got_ll == ll
+
+
+@pytest.mark.parametrize("stk,gold", [("tiny.stk", "tiny.params.json"), ("test.stk", "test.params.json")])
+def test_fit_error_goldens(oracle_mod, ref_data, stk, gold):
+    O = oracle_mod
+    pairs = [O.alignment_pair(r) for r in O.read_stockholm(os.path.join(ref_data, stk))]
+    fit = O.baum_welch(O.MutatorParams.from_cli(), pairs, strict=True)
+    assert O.params_json(fit) == open(os.path.join(ref_data, gold)).read()
+
+
+def test_log_sum_exp_table_semantics(oracle_mod):
+    # logsumexp.h:34-54: table step 1e-4, linear interpolation, exactly 0 from x = 10 on
+    O = oracle_mod
+    L = O.lib()
+    import ctypes
+    L.orc_log_sum_exp.restype = ctypes.c_double
+    f = lambda a, b: L.orc_log_sum_exp(ctypes.c_double(a), ctypes.c_double(b))
+    assert f(0.0, 0.0) == math.log(2.0)
+    assert f(0.0, -10.0) == 0.0 and f(-3.0, -13.5) == -3.0
+    assert f(-math.inf, -math.inf) == -math.inf and f(1.5, -math.inf) == 1.5
+    assert abs(f(0.0, -1.00005) - math.log1p(math.exp(-1.00005))) < 1e-8
+    assert f(0.0, -1.00005) != math.log1p(math.exp(-1.00005))       # interpolated, not exact
