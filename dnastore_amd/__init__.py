@@ -6,6 +6,6 @@ operator surface used by tests and bench.py: Machine (src/trans.h), MutatorParam
 (src/mutator.h) and decodeFastSeqs / ViterbiMatrix (src/viterbi.h:94-108).
 """
 from .api import (FlatModel, Machine, MutatorParams, StockholmDB, ViterbiDecoder, baumWelchParams, countsJSON,  # noqa: F401
-                  decode_fastseqs, expectedCounts, paramsJSON,
+                  decode_fastseqs, expectedCounts, paramsJSON, symbolsToBytes,
                   pack_reads, read_fastseqs, tokenize)
 from .lib import DnasError, LIB_PATH  # noqa: F401

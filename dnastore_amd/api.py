@@ -47,6 +47,17 @@ class Machine:
         _l.lib().dnas_free(p)
         return s
 
+    @staticmethod
+    def compose(first, second):
+        """Machine::compose(first, second) (trans.cpp:505-602)."""
+        h = ctypes.c_void_p()
+        _l.check(_l.lib().dnas_machine_compose(first._h, second._h, ctypes.byref(h)))
+        return Machine(h)
+
+    def decodeExact(self, dna):
+        """Decoder<ostream>::decodeString + close (decoder.h:123-190): DNA -> symbol string."""
+        return self._encode(_l.lib().dnas_decode_exact, dna.encode() if isinstance(dna, str) else dna)
+
     def encodeSymbols(self, symbols):
         """Encoder::encodeSymbolString + close (encoder.h:33-57,238-241) -> DNA string."""
         return self._encode(_l.lib().dnas_encode_symbols, symbols.encode() if isinstance(symbols, str) else symbols)
@@ -314,3 +325,13 @@ def countsJSON(counts, n_len):
     buf = ctypes.create_string_buffer(8192)
     _l.check(_l.lib().dnas_mutator_counts_json(c.ctypes.data, int(n_len), buf, 8192))
     return buf.value.decode()
+
+
+def symbolsToBytes(symbols):
+    """BinaryWriter (decoder.h:193-240): '0'/'1' symbols -> bytes, LSB first; other symbols ignored."""
+    b = symbols.encode() if isinstance(symbols, str) else symbols
+    p, n = ctypes.c_void_p(), ctypes.c_size_t()
+    _l.check(_l.lib().dnas_symbols_to_bytes(b, len(b), ctypes.byref(p), ctypes.byref(n)))
+    out = ctypes.string_at(p, n.value)
+    _l.lib().dnas_free(p)
+    return out

@@ -9,6 +9,7 @@
 
 #include "../../include/dnastore_amd.h"
 #include "errors.hpp"
+#include "host/decoder.hpp"
 #include "host/encoder.hpp"
 #include "host/fastseq.hpp"
 #include "host/machine.hpp"
@@ -121,6 +122,44 @@ int dnas_encode_bytes(const dnas_machine* m, const uint8_t* bytes, size_t n, cha
     dnas::Encoder enc(m->machine);
     enc.encodeBytes(std::string((const char*)bytes, n));
     return encoded_to_c(enc, out_dna, out_len);
+  });
+}
+
+int dnas_machine_compose(const dnas_machine* first, const dnas_machine* second, dnas_machine** out) {
+  if (!first || !second || !out) return dnas::fail(DNAS_E_INVALID, "null argument");
+  *out = nullptr;
+  return guarded([&] {
+    *out = new dnas_machine{dnas::Machine::compose(first->machine, second->machine)};
+    return DNAS_OK;
+  });
+}
+
+int dnas_decode_exact(const dnas_machine* m, const char* dna, size_t n, char** out_symbols, size_t* out_len) {
+  if (!m || (!dna && n) || !out_symbols || !out_len) return dnas::fail(DNAS_E_INVALID, "null argument");
+  return guarded([&] {
+    dnas::Decoder dec(m->machine);
+    dec.decodeString(std::string(dna, n));
+    dec.close();
+    const std::string& s = dec.symbols();
+    char* buf = (char*)malloc(s.size() + 1);
+    if (!buf) throw std::bad_alloc();
+    memcpy(buf, s.c_str(), s.size() + 1);
+    *out_symbols = buf;
+    *out_len = s.size();
+    return DNAS_OK;
+  });
+}
+
+int dnas_symbols_to_bytes(const char* symbols, size_t n, uint8_t** out_bytes, size_t* out_len) {
+  if ((!symbols && n) || !out_bytes || !out_len) return dnas::fail(DNAS_E_INVALID, "null argument");
+  return guarded([&] {
+    const std::string b = dnas::symbolsToBytes(std::string(symbols, n));
+    uint8_t* buf = (uint8_t*)malloc(b.size() + 1);
+    if (!buf) throw std::bad_alloc();
+    memcpy(buf, b.data(), b.size());
+    *out_bytes = buf;
+    *out_len = b.size();
+    return DNAS_OK;
   });
 }
 

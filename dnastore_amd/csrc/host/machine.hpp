@@ -49,6 +49,14 @@ struct Machine {
   // "Transducer is cyclic, can't toposort" (trans.cpp:604-634).
   std::vector<uint32_t> decoderToposort(const std::string& inputAlphabet) const;
 
+  // Composition first*second (first's output feeds second's input): product states i*|B|+j,
+  // B turned into a waiting machine first, unreachable / dead-end states pruned, chains of lone
+  // null transitions collapsed (reference Machine::compose, trans.cpp:505-602).  State names,
+  // order and transition order follow the reference so that the saved JSON is identical.
+  static Machine compose(const Machine& first, const Machine& second);
+  Machine waitingMachine() const;                        // trans.cpp:636-670
+  bool isWaitingMachine() const;                         // trans.cpp:498-503
+
   static bool isControl(char c) { return c >= 'A' && c <= 'Z'; }
   static bool isRelaxed(char c) { return c == '0' || c == '1'; }
   static bool isStrict(char c) {

@@ -83,6 +83,9 @@ def lib():
         "dnas_machine_free": (None, [vp]),
         "dnas_machine_n_states": (ctypes.c_int32, [vp]),
         "dnas_machine_write_json": (ctypes.c_int, [vp, P(vp), P(sz)]),
+        "dnas_machine_compose": (ctypes.c_int, [vp, vp, P(vp)]),
+        "dnas_decode_exact": (ctypes.c_int, [vp, cp, sz, P(vp), P(sz)]),
+        "dnas_symbols_to_bytes": (ctypes.c_int, [cp, sz, P(vp), P(sz)]),
         "dnas_encode_symbols": (ctypes.c_int, [vp, cp, sz, P(vp), P(sz)]),
         "dnas_encode_bytes": (ctypes.c_int, [vp, cp, sz, P(vp), P(sz)]),
         "dnas_mutator_params_from_flags": (ctypes.c_int, [ctypes.c_double] * 5 + [ctypes.c_int, ctypes.c_int, P(MutatorParamsC)]),

@@ -11,10 +11,14 @@ import torch.distributed as dist
 
 
 def partition(lengths, world):
-    """Deal reads to ranks so that every rank gets the same count and a similar length mix:
-    sort by length (longest first) and deal round-robin.  Returns a list of index arrays."""
+    """Deal reads to ranks so that every rank gets the same count (+-1) and a similar length mix:
+    sort by length (longest first) and deal in snake order (0..W-1, W-1..0, ...).  Returns index arrays."""
     order = np.argsort(-np.asarray(lengths, dtype=np.int64), kind="stable")
-    return [np.sort(order[r::world]) for r in range(world)]
+    parts = [[] for _ in range(world)]
+    for pos, i in enumerate(order):
+        rnd, k = divmod(pos, world)
+        parts[k if rnd % 2 == 0 else world - 1 - k].append(int(i))
+    return [np.sort(np.array(p, dtype=np.int64)) for p in parts]
 
 
 def _dist_ready(world):

@@ -99,6 +99,14 @@ int dnas_machine_write_json(const dnas_machine *m, char **out_text, size_t *out_
 int dnas_encode_symbols(const dnas_machine *m, const char *symbols, size_t n_symbols, char **out_dna, size_t *out_len);
 int dnas_encode_bytes(const dnas_machine *m, const uint8_t *bytes, size_t n_bytes, char **out_dna, size_t *out_len);
 
+/* Machine::compose(first, second) (trans.cpp:505-602): first's output feeds second's input. */
+int dnas_machine_compose(const dnas_machine *first, const dnas_machine *second, dnas_machine **out);
+
+/* Exact decoder (reference Decoder<W>, src/decoder.h:7-191): DNA -> input symbols (malloc'd string),
+ * and BinaryWriter (decoder.h:193-240): '0'/'1' symbols -> bytes, LSB first (malloc'd, *out_len bytes). */
+int dnas_decode_exact(const dnas_machine *m, const char *dna, size_t n, char **out_symbols, size_t *out_len);
+int dnas_symbols_to_bytes(const char *symbols, size_t n, uint8_t **out_bytes, size_t *out_len);
+
 /* Error model from the CLI flags (t/dnastore.cpp:119-129): --error-sub-prob, --error-iv-ratio,
  * --error-dup-prob, --error-del-open, --error-del-ext, --error-global, --length. */
 int dnas_mutator_params_from_flags(double sub_prob, double iv_ratio, double dup_prob, double del_open,
