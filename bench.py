@@ -168,6 +168,16 @@ def main():
         value = total_nt * args.steps / elapsed
         launches = stats["fill_launches"] * args.steps
         achieved = stats["lattice_bytes"] * args.steps / (fill_ms / 1e3) / 1e9 if fill_ms > 0 else 0.0
+        # HBM traffic of the fill kernel: PMC counters are collected in separate rocprofv3 passes of this same
+        # command (profiles/r1_traffic.json: FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md, + WRITE_SIZE,
+        # in KB), recorded per lattice column and scaled here to the columns of one launch
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+            if tj.get("kernel", "").endswith("tiera") == dec.tier.startswith("tier A"):
+                traffic = tj["hbm_bytes_per_column_corrected"] * stats["columns"] / max(stats["fill_launches"], 1)
+        except (OSError, ValueError, KeyError):
+            pass
         line = {
             "metric": "decoded nt/sec (whole node), Viterbi on composite FST",
             "value": value, "unit": "nt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -177,7 +187,7 @@ def main():
                                    "--error-global, 1%% substitutions" % args.reads,
                        "reads_per_gpu": args.reads, "total_nt": int(total_nt), "parallelism": "read-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "viterbi_fill_tiera" if dec.tier.startswith("tier A") else "viterbi_fill_kernel",
                          "tier": dec.tier[:6], "avg_launch_ms": fill_ms / max(launches, 1),
                          "algorithmic_bytes_per_launch": stats["lattice_bytes"] / max(stats["fill_launches"], 1),

@@ -143,6 +143,15 @@ class FlatModel:
                             + [v.len[i] for i in range(v.n_len)]),
             alphabet=v.alphabet.decode(), sym_logp=np.array(list(v.sym_logp)))
 
+    def plan_slots(self):
+        """Tier-A placement: (lds_index int32[N] = row*T + lane, lattice_slot int32[N], T, K)."""
+        n = self.view.contents.n_states
+        lds = np.full(n, -1, dtype=np.int32)
+        lat = np.full(n, -1, dtype=np.int32)
+        t, k = ctypes.c_int32(), ctypes.c_int32()
+        _l.check(_l.lib().dnas_tiera_plan_slots(self.view, lds.ctypes.data, lat.ctypes.data, ctypes.addressof(t), ctypes.addressof(k)))
+        return lds, lat, t.value, k.value
+
     def precompile(self):
         """JIT-specialise the tier-A fill kernel for this machine into dnastore_amd/kcache (no GPU needed)."""
         buf = ctypes.create_string_buffer(1024)

@@ -469,3 +469,23 @@ extern "C" int dnas_model_debug_words(dnas_model* m, unsigned long long* out8) {
   HIP_TRY(hipMemcpy(out8, m->dRounds, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return DNAS_OK;
 }
+
+// Analysis / test aid: the tier-A placement of a machine (no GPU needed).  lds_index[N] receives
+// row*T + lane of every state; returns T in *threads and K in *rows; DNAS_E_UNSUPPORTED when the
+// machine does not fit tier A.
+extern "C" int dnas_tiera_plan_slots(const dnas_flat_model* fm, int32_t* lds_index, int32_t* lattice_slot, int32_t* threads,
+                                     int32_t* rows) {
+  if (!fm) return dnas::fail(DNAS_E_INVALID, "null argument");
+  try {
+    const dnas::TierAPlan p = dnas::buildTierAPlan(*fm);
+    if (!p.ok) return dnas::fail(DNAS_E_UNSUPPORTED, p.whyNot);
+    if (threads) *threads = p.T;
+    if (rows) *rows = p.K;
+    for (int slot = 0; slot < p.NS; ++slot)
+      if (p.stateOf[slot] >= 0 && lds_index) lds_index[p.stateOf[slot]] = slot;
+    if (lattice_slot) for (int j = 0; j < p.N; ++j) lattice_slot[j] = p.slotOf[j];
+    return DNAS_OK;
+  } catch (const std::exception& e) {
+    return dnas::fail(DNAS_E_DEVICE, e.what());
+  }
+}

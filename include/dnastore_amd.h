@@ -156,6 +156,11 @@ const char *dnas_model_tier(const dnas_model *model);
 /* Specialise + compile the tier-A kernel for a machine ahead of time (no GPU needed). */
 int dnas_tiera_precompile(const dnas_flat_model *fm, char *note, size_t note_cap);
 
+/* Analysis / test aid: where tier A puts each state (lds_index = row*threads + lane; lattice_slot = its
+ * position inside a lattice row).  No GPU needed.  DNAS_E_UNSUPPORTED when the machine does not fit tier A. */
+int dnas_tiera_plan_slots(const dnas_flat_model *fm, int32_t *lds_index, int32_t *lattice_slot, int32_t *threads,
+                          int32_t *rows);
+
 /* Diagnostic: 8 words of the kernel's rounds/stamp buffer (word 0 = total rounds; words 1-5 are filled only by
  * a -DDNAS_STAMP diagnostic build selected with DNAS_TIERA_DEFS). */
 int dnas_model_debug_words(dnas_model *model, unsigned long long *out8);
