@@ -61,7 +61,9 @@ struct dnas_model {
   TierAArgs argsA{};
   unsigned *dEntTab = nullptr, *dMetaTab = nullptr, *dBaseTab = nullptr;
   int32_t* dSlotOf = nullptr;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;     // fill kernels
+  hipStream_t stream2 = nullptr;    // traceback kernels (batch i traces back while batch i+1 fills)
+  std::vector<hipEvent_t> sync;     // 2 per batch: fill done, traceback done
   DevModel dm{};
   std::vector<void*> owned;   // device allocations of the tables
   double* arena = nullptr;
@@ -72,12 +74,13 @@ struct dnas_model {
   int32_t* dBatchRead = nullptr;
   uint64_t *dSlotOff = nullptr, *dReadOff = nullptr, *dOutOff = nullptr;
   size_t schedCap = 0;
+  size_t halfDoubles = 0;              // size of one arena half (doubles)
   std::vector<uint64_t> lastSlotOff;   // host copy, sorted-batch order of the last call
   std::vector<int32_t> lastBatchRead;
   std::vector<uint64_t> lastReadOff;   // host copy of the last call's read offsets
   const uint8_t* lastBases = nullptr;  // device pointer of the last call's bases (valid while the caller keeps it)
   uint8_t* keepBases = nullptr;        // dnas_viterbi_batch's own copy, kept until the next call (lattice export)
-  std::vector<hipEvent_t> events;      // 3 per batch: start, after fill, after traceback
+  std::vector<hipEvent_t> events;      // 4 per batch: fill start/end (stream), traceback start/end (stream2)
   dnas_batch_stats stats{};
   bool statsPending = false;
 };
@@ -97,10 +100,10 @@ int upload(dnas_model* m, const T* host, size_t n, const T** out) {
 int collect_stats(dnas_model* m) {
   if (!m->statsPending) return DNAS_OK;
   m->stats.fill_ms = m->stats.traceback_ms = 0;
-  for (size_t i = 0; i + 3 <= m->events.size(); i += 3) {
+  for (size_t i = 0; i + 4 <= m->events.size(); i += 4) {
     float a = 0, b = 0;
     HIP_TRY(hipEventElapsedTime(&a, m->events[i], m->events[i + 1]));
-    HIP_TRY(hipEventElapsedTime(&b, m->events[i + 1], m->events[i + 2]));
+    HIP_TRY(hipEventElapsedTime(&b, m->events[i + 2], m->events[i + 3]));
     m->stats.fill_ms += a;
     m->stats.traceback_ms += b;
   }
@@ -127,7 +130,8 @@ extern "C" int dnas_model_create(const dnas_flat_model* fm, int device_id, size_
   dnas_model* m = new dnas_model();
   m->device = device_id;
   auto bail = [&](int rc) { dnas_model_destroy(m); return rc; };
-  if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess)
+  if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking) != hipSuccess)
     return bail(dnas::fail(DNAS_E_DEVICE, "hipStreamCreate failed"));
   const int N = fm->n_states, D = fm->max_dup_len;
   DevModel& d = m->dm;
@@ -214,6 +218,9 @@ extern "C" void dnas_model_destroy(dnas_model* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   if (m->stream) (void)hipStreamSynchronize(m->stream);
+  if (m->stream2) (void)hipStreamSynchronize(m->stream2);
+  for (hipEvent_t e : m->sync) (void)hipEventDestroy(e);
+  if (m->stream2) (void)hipStreamDestroy(m->stream2);
   for (void* p : m->owned) (void)hipFree(p);
   if (m->arena) (void)hipFree(m->arena);
   if (m->dRounds) (void)hipFree(m->dRounds);
@@ -236,6 +243,7 @@ extern "C" int dnas_model_sync(dnas_model* m) {
   if (!m) return dnas::fail(DNAS_E_INVALID, "null model");
   HIP_TRY(hipSetDevice(m->device));
   HIP_TRY(hipStreamSynchronize(m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream2));
   return collect_stats(m);
 }
 
@@ -255,6 +263,7 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
   HIP_TRY(hipSetDevice(m->device));
   // the previous call's events/stat buffers are about to be reused
   HIP_TRY(hipStreamSynchronize(m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream2));
   m->stats = dnas_batch_stats{};
   m->statsPending = false;
   if (n_reads == 0) return DNAS_OK;
@@ -268,7 +277,8 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
   std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
     return read_offsets[a + 1] - read_offsets[a] > read_offsets[b + 1] - read_offsets[b];
   });
-  const size_t arenaCapDoubles = m->arenaCap / sizeof(double);
+  // two arena halves: batch i fills half (i & 1) while the traceback of batch i-1 still reads the other
+  const size_t arenaCapDoubles = m->arenaCap / sizeof(double) / 2;
   std::vector<uint64_t> slotOff((size_t)n_reads);
   std::vector<int64_t> batchStart{0};
   size_t used = 0, peak = 0;
@@ -290,13 +300,15 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
     columns += (int64_t)L + 1;
   }
   batchStart.push_back(n_reads);
-  if (peak * sizeof(double) > m->arenaBytes) {
+  const bool pingPong = batchStart.size() > 2;          // more than one batch
+  if ((pingPong ? 2 : 1) * peak * sizeof(double) > m->arenaBytes) {
     if (m->arena) HIP_TRY(hipFree(m->arena));
     m->arena = nullptr;
     m->arenaBytes = 0;
-    HIP_TRY(hipMalloc((void**)&m->arena, peak * sizeof(double)));
-    m->arenaBytes = peak * sizeof(double);
+    HIP_TRY(hipMalloc((void**)&m->arena, (pingPong ? 2 : 1) * peak * sizeof(double)));
+    m->arenaBytes = (pingPong ? 2 : 1) * peak * sizeof(double);
   }
+  m->halfDoubles = peak;
   if ((size_t)n_reads + 1 > m->schedCap) {
     if (m->dBatchRead) { (void)hipFree(m->dBatchRead); (void)hipFree(m->dSlotOff); (void)hipFree(m->dReadOff); (void)hipFree(m->dOutOff); }
     m->dBatchRead = nullptr; m->dSlotOff = m->dReadOff = m->dOutOff = nullptr;
@@ -320,17 +332,31 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
   HIP_TRY(hipMemsetAsync(m->dRounds, 0, 8 * sizeof(unsigned long long), m->stream));
 
   const size_t nBatches = batchStart.size() - 1;
-  while (m->events.size() < 3 * nBatches) {
+  while (m->events.size() < 4 * nBatches) {
     hipEvent_t e;
     HIP_TRY(hipEventCreate(&e));
     m->events.push_back(e);
   }
+  while (m->sync.size() < 2 * nBatches) {
+    hipEvent_t e;
+    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    m->sync.push_back(e);
+  }
   const int maskWords = (d.N + 31) / 32 + 1;
   const size_t ldsBytes = 2 * (size_t)maskWords * sizeof(unsigned);
+  // slot offsets of odd batches point into the second half
+  if (pingPong) {
+    for (size_t b = 1; b < nBatches; b += 2)
+      for (int64_t i = batchStart[b]; i < batchStart[b + 1]; ++i) slotOff[(size_t)i] += m->halfDoubles;
+    m->lastSlotOff = slotOff;
+    HIP_TRY(hipMemcpy(m->dSlotOff, slotOff.data(), (size_t)n_reads * sizeof(uint64_t), hipMemcpyHostToDevice));
+  }
   for (size_t b = 0; b < nBatches; ++b) {
     const int64_t s = batchStart[b];
     const int nB = (int)(batchStart[b + 1] - s);
-    HIP_TRY(hipEventRecord(m->events[3 * b], m->stream));
+    // the half this batch fills was last read by the traceback of batch b-2
+    if (b >= 2) HIP_TRY(hipStreamWaitEvent(m->stream, m->sync[2 * (b - 2) + 1], 0));
+    HIP_TRY(hipEventRecord(m->events[4 * b], m->stream));
     if (m->tier == 1) {
       TierALaunch la{m->argsA, m->dEntTab, m->dMetaTab, m->dBaseTab, d_bases, m->dReadOff, m->dBatchRead + s, m->dSlotOff + s,
                      m->arena, d_out_loglike, m->dRounds};
@@ -344,16 +370,20 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
                          (const uint64_t*)(m->dSlotOff + s), m->arena, d_out_loglike, m->dRounds, maskWords);
       HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipEventRecord(m->events[3 * b + 1], m->stream));
+    HIP_TRY(hipEventRecord(m->events[4 * b + 1], m->stream));
+    HIP_TRY(hipEventRecord(m->sync[2 * b], m->stream));
+    HIP_TRY(hipStreamWaitEvent(m->stream2, m->sync[2 * b], 0));
+    HIP_TRY(hipEventRecord(m->events[4 * b + 2], m->stream2));
     hipLaunchKernelGGL(viterbi_traceback_kernel, dim3((nB + kTraceThreads - 1) / kTraceThreads), dim3(kTraceThreads), 0,
-                       m->stream, d, d_bases, (const uint64_t*)m->dReadOff, (const int32_t*)(m->dBatchRead + s),
+                       m->stream2, d, d_bases, (const uint64_t*)m->dReadOff, (const int32_t*)(m->dBatchRead + s),
                        (const uint64_t*)(m->dSlotOff + s), (const double*)m->arena, d_out_sym,
                        (const uint64_t*)m->dOutOff, d_out_len, d_out_status, nB);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(m->events[3 * b + 2], m->stream));
+    HIP_TRY(hipEventRecord(m->events[4 * b + 3], m->stream2));
+    HIP_TRY(hipEventRecord(m->sync[2 * b + 1], m->stream2));
   }
   // trim so collect_stats sees exactly this call's events
-  while (m->events.size() > 3 * nBatches) {
+  while (m->events.size() > 4 * nBatches) {
     (void)hipEventDestroy(m->events.back());
     m->events.pop_back();
   }
