@@ -203,15 +203,18 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
   };
   p.entTab.assign((size_t)p.nEntries * T, 0);
   p.metaTab.assign((size_t)K * T, 0);
-  p.baseTab.assign((size_t)K * T, 0);
+  int totalEmitSlots = 0;
+  for (const RowShape& r : p.rows) totalEmitSlots += r.e[0] + r.e[1] + r.e[2] + r.e[3];
+  p.nBaseWords = std::max(1, (totalEmitSlots + 15) / 16);
+  p.baseTab.assign((size_t)p.nBaseWords * T, 0);
+  int emitSlotBase = 0;
   int off = 0;
   for (int k = 0; k < K; ++k) {
     const RowShape& r = p.rows[k];
     for (int t = 0; t < T; ++t) {
       const int j = p.stateOf[(size_t)k * T + t];
       int m = off;
-      unsigned bases = 0;
-      int epos = 0;
+      int epos = emitSlotBase;
       for (int s = 0; s < 4; ++s) {
         std::vector<const Pull*> mine;            // this state's emit pulls of class s, reference edge order
         if (j >= 0 && !heavy[j])
@@ -220,7 +223,7 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
           unsigned v = (unsigned)p.xDummy * 8u;
           if (e < (int)mine.size()) {
             v = (unsigned)ldsIdx[mine[e]->src] * 8u;
-            bases |= (unsigned)(mine[e]->base & 3) << (2 * epos);
+            p.baseTab[(size_t)(epos / 16) * T + t] |= (unsigned)(mine[e]->base & 3) << (2 * (epos % 16));
           }
           p.entTab[(size_t)m * T + t] = v;
         }
@@ -257,9 +260,9 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
         meta |= 0x20000000u;   // slot holds a real state
       }
       p.metaTab[(size_t)k * T + t] = meta;
-      p.baseTab[(size_t)k * T + t] = bases;
     }
     off += rowEntries(r);
+    emitSlotBase += r.e[0] + r.e[1] + r.e[2] + r.e[3];
   }
 
   // LDS cost model of one sweep's gathers: a ds_read_b64 is served per 32-lane half in as many
@@ -301,7 +304,7 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
     rows << "{{" << r.e[0] << "," << r.e[1] << "," << r.e[2] << "," << r.e[3] << "},{" << r.n[0] << "," << r.n[1] << ","
          << r.n[2] << "," << r.n[3] << "}," << r.ep << "," << r.ec << "}";
   }
-  defs << "-DDNAS_T=" << T << "\n-DDNAS_K=" << K << "\n-DDNAS_D=" << D << "\n-DDNAS_NS=" << p.NS << "\n-DDNAS_C=" << C
+  defs << "-DDNAS_BASEWORDS=" << p.nBaseWords << "\n-DDNAS_T=" << T << "\n-DDNAS_K=" << K << "\n-DDNAS_D=" << D << "\n-DDNAS_NS=" << p.NS << "\n-DDNAS_C=" << C
        << "\n-DDNAS_ROWS=" << rows.str();
   p.defines = defs.str();
   p.key = "T" + std::to_string(T) + "K" + std::to_string(K) + "D" + std::to_string(D) + "NS" + std::to_string(p.NS) + "C" +

@@ -33,7 +33,8 @@ struct TierAPlan {
   std::vector<int32_t> stateOf;   // [NS] LDS index (row*T + lane) -> state or -1
   std::vector<uint32_t> entTab;   // [nEntries][T]
   std::vector<uint32_t> metaTab;  // [K][T]  mdl | ctx<<4 | flags
-  std::vector<uint32_t> baseTab;  // [K][T]  emitted base of each emit pull of the row, 2 bits each
+  std::vector<uint32_t> baseTab;  // [nBaseWords][T]  emitted base of the thread's i-th emit pull, 2 bits each, 16 per word
+  int nBaseWords = 1;
   double score[4] = {0, 0, 0, 0};
   size_t ldsBytes = 0;
   double fillRatio = 0;           // real entries / padded entries

@@ -52,6 +52,11 @@ constexpr int nullClass(int k, int e) {
   return c;
 }
 constexpr int kEntries = rowOffset(DNAS_K) > 0 ? rowOffset(DNAS_K) : 1;
+constexpr int emitSlotBase(int k) {
+  int o = 0;
+  for (int i = 0; i < k; ++i) o += rowEE(i);
+  return o;
+}
 constexpr int maxRowVals() {
   int m = 0;
   for (int k = 0; k < DNAS_K; ++k) m = rowEE(k) + 2 * rowEN(k) > m ? rowEE(k) + 2 * rowEN(k) : m;
@@ -128,7 +133,7 @@ constexpr double kNegInf = -__builtin_huge_val();
 extern "C" __global__ void __launch_bounds__(DNAS_T)
 viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntries][T]
                    const unsigned* __restrict__ metaTab,                // [K][T]: mdl | ctx<<4 | flags
-                   const unsigned* __restrict__ baseTab,                // [K][T]: base of each emit pull, 2 bits each
+                   const unsigned* __restrict__ baseTab,                // [DNAS_BASEWORDS][T]: base of each emit pull, 2 bits each
                    const unsigned char* __restrict__ bases, const unsigned long long* __restrict__ readOff,
                    const int* __restrict__ batchRead, const unsigned long long* __restrict__ slotOff,
                    double* __restrict__ arena, double* __restrict__ outLoglike,
@@ -155,9 +160,11 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
   unsigned E[kEntries];
   static_for<0, kEntries>([&](auto m) { E[m.value] = entTab[(size_t)m.value * T + tid]; });
 #define META(k) (metaTab[(size_t)(k) * T + tid])
+  unsigned baseW[DNAS_BASEWORDS];   // emitted base of every emit pull of this thread, 2 bits each (phase A)
+  static_for<0, DNAS_BASEWORDS>([&](auto w) { baseW[w.value] = baseTab[(size_t)w.value * T + tid]; });
   const double scoreC[4] = {0.0, a.score[1], a.score[2], a.score[3]};
 
-  double S[K], Dv[K], tc[K];
+  double S[K], Dv[K];   // after phase C, Dv[k] carries the T1 hand-over to the next column's phase A
   unsigned rounds = 0;
 #ifdef DNAS_STAMP   // diagnostic build: where does a column spend its cycles (never in the shipped kernel)
   unsigned long long tA = 0, tP = 0, tB = 0, tC = 0, t0 = 0, t1 = 0;
@@ -176,17 +183,15 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
 
   // The S and D lanes of column p leave for HBM from the registers, 16 bytes per lane (rows 2m and
   // 2m+1 of a thread are lattice neighbours).
-#define STORE_COLUMN(p)                                                                          \
+#define STORE_LANE(p, lane, REG)                                                                 \
   {                                                                                              \
-    double* const colp = lat + (size_t)(p) * lanes * NS;                                         \
+    double* const colp = lat + ((size_t)(p) * lanes + (lane)) * NS;                              \
     static_for<0, K / 2>([&](auto mc) {                                                          \
       constexpr int m2 = mc.value;                                                               \
       if (pairValid & (1u << m2)) {                                                              \
-        dbl2 sv, dv;                                                                             \
-        sv.x = S[2 * m2]; sv.y = S[2 * m2 + 1];                                                  \
-        dv.x = Dv[2 * m2]; dv.y = Dv[2 * m2 + 1];                                                \
-        reinterpret_cast<dbl2*>(colp + (size_t)m2 * 2 * T)[tid] = sv;                            \
-        reinterpret_cast<dbl2*>(colp + (size_t)NS + (size_t)m2 * 2 * T)[tid] = dv;               \
+        dbl2 v2;                                                                                 \
+        v2.x = REG[2 * m2]; v2.y = REG[2 * m2 + 1];                                              \
+        reinterpret_cast<dbl2*>(colp + (size_t)m2 * 2 * T)[tid] = v2;                            \
       }                                                                                          \
     });                                                                                          \
   }
@@ -203,7 +208,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
 #endif
 
     // ---- phase A (viterbi.cpp:75-79,92-95,101-103): S of this column from the previous
-    // column's S (parked in X[] by phase C) and the T1 lane (handed over in tc[] by phase C).
+    // column's S (parked in X[] by phase C) and the T1 lane (handed over in the D registers by phase C).
     // Heavy destinations receive their emit-in candidates by ds_max pushes into SN[cell]
     // (their owners reset the cell in phase C).
     if (pos > 0) {
@@ -217,20 +222,16 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
           }
         });
       });
-      unsigned bases[K];
-      static_for<0, K>([&](auto kc) {
-        constexpr int k = kc.value;
-        if constexpr (rowEE(k) > 0) bases[k] = baseTab[(size_t)k * T + tid];
-      });
       static_for<0, K>([&](auto kc) {
         constexpr int k = kc.value, o = rowOffset(k);
-        double s = tc[k];
+        double s = Dv[k];   // T1(pos-1) + sub[ctx1][x_pos], left there by phase C
         static_for<0, rowEE(k)>([&](auto ec) {
           constexpr int cls = emitClass(k, ec.value);
           // (S(src) + score) + noGap + sub: "+ 0.0" of class 0 is the identity on every value that occurs
           double v = ldsRead(ldsB, E[o + ec.value]);
           if constexpr (cls != 0) v = v + scoreC[cls];
-          s = dmax(s, (v + a.noGap) + subL[((bases[k] >> (2 * ec.value)) & 3u) * 4 + x]);
+          constexpr int slot = emitSlotBase(k) + ec.value;   // this thread's slot-th emit pull overall
+          s = dmax(s, (v + a.noGap) + subL[((baseW[slot / 16] >> (2 * (slot % 16))) & 3u) * 4 + x]);
         });
         S[k] = s;
       });
@@ -386,6 +387,9 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
     // any T cell it visits the same way.  The S history comes back from HBM/L2 (this thread
     // wrote it), a group of rows per memory latency.
     {
+      // the D lane leaves first: its registers then carry the T1 hand-over (one store latency ahead
+      // of the history loads, instead of 28 more live registers)
+      STORE_LANE(pos, 1, Dv)
       const int xn = pos < L ? seq[pos] : 0;
       int xh[D_ > 0 ? D_ : 1];   // xh[i] = x_{pos-i}
       static_for<0, D_>([&](auto ic) { xh[ic.value] = pos - ic.value >= 1 ? seq[pos - ic.value - 1] : 0; });
@@ -456,12 +460,12 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
             });
           }
           // next column: S >= T1(pos) + sub[ctx1][x_{pos+1}]   (viterbi.cpp:101-103)
-          tc[k] = (valid && mdl > 0) ? v + subL[((metaG[k - k0] >> 4) & 3u) * 4 + xn] : kNegInf;
+          Dv[k] = (valid && mdl > 0) ? v + subL[((metaG[k - k0] >> 4) & 3u) * 4 + xn] : kNegInf;   // D(pos) is already on its way to HBM
         });
       });
-      // all of the column's stores go out last: a wave's memory operations return in order, so a
-      // store issued between two groups would sit in front of the next group's history loads
-      STORE_COLUMN(pos)
+      // the S lane goes out last: a wave's memory operations return in order, so a store issued
+      // between two groups would sit in front of the next group's history loads
+      STORE_LANE(pos, 0, S)
     }
     __syncthreads();   // X[] now holds S(pos) for everyone
     STAMP(tC)
