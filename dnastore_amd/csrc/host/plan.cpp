@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <array>
 #include <cstring>
+#include <map>
 #include <numeric>
 #include <sstream>
 
@@ -89,15 +90,82 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
     c[9] = hasCell[j] ? 1 : 0;
     cnt[j] = c;
   }
-  // Rows come out (nearly) homogeneous when identical count vectors sit together; ordering the
-  // classes by (scored emit pulls, scored null pulls, plain null pulls, plain emit pulls, ...)
-  // gave the least padding on the reference's composites.  Ties keep reference state order.
-  auto sortKey = [&](const Counts& c) {
-    return std::array<int, 10>{c[1], c[2], c[3], c[5], c[6], c[7], c[4], c[0], c[8], c[9]};
-  };
+  // Rows come out (nearly) homogeneous when identical count vectors ("classes") sit together.
+  // The ORDER of the classes decides how far a value travels inside one sweep: rows run in
+  // order, so an edge from an earlier row to a later one is relaxed in the same sweep while an
+  // edge pointing back costs another sweep.  The classes are few: the order that minimises the
+  // number of backward edges between classes is found by exhaustive search over the eight
+  // largest classes (the rest keep a descending-cost order behind them); inside a class, states
+  // follow a depth-first pre-order of the machine so that chains run forward as well.
   std::vector<int> order(N);
-  std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sortKey(cnt[a]) > sortKey(cnt[b]); });
+  {
+    std::map<Counts, int> classId;
+    std::vector<Counts> classes;
+    std::vector<int> cls(N), size;
+    for (int j = 0; j < N; ++j) {
+      auto it = classId.find(cnt[j]);
+      if (it == classId.end()) { it = classId.emplace(cnt[j], (int)classes.size()).first; classes.push_back(cnt[j]); size.push_back(0); }
+      cls[j] = it->second;
+      ++size[cls[j]];
+    }
+    const int nC = (int)classes.size();
+    std::vector<std::vector<long>> w(nC, std::vector<long>(nC, 0));   // edges class a -> class b
+    for (int j = 0; j < N; ++j) {
+      for (const Pull& q : emitIn[j]) ++w[cls[q.src]][cls[j]];
+      for (const Pull& q : nullIn[j]) ++w[cls[q.src]][cls[j]];
+    }
+    std::vector<int> bySize(nC);
+    std::iota(bySize.begin(), bySize.end(), 0);
+    std::stable_sort(bySize.begin(), bySize.end(), [&](int a, int b) { return size[a] > size[b]; });
+    const int nTop = std::min(nC, 8);
+    std::vector<int> top(bySize.begin(), bySize.begin() + nTop), best;
+    std::sort(top.begin(), top.end());
+    long bestCost = -1;
+    do {
+      long cost = 0;
+      for (int a = 0; a < nTop; ++a)
+        for (int b = 0; b < a; ++b) cost += w[top[a]][top[b]];        // from a later class back to an earlier one
+      if (bestCost < 0 || cost < bestCost) { bestCost = cost; best = top; }
+    } while (std::next_permutation(top.begin(), top.end()));
+    std::vector<int> rank(nC, 0);
+    for (int i = 0; i < nTop; ++i) rank[best[i]] = i;
+    {
+      std::vector<int> rest(bySize.begin() + nTop, bySize.end());
+      auto key = [&](const Counts& c) { return std::array<int, 10>{c[1], c[2], c[3], c[5], c[6], c[7], c[4], c[0], c[8], c[9]}; };
+      std::stable_sort(rest.begin(), rest.end(), [&](int a, int b) { return key(classes[a]) > key(classes[b]); });
+      for (size_t i = 0; i < rest.size(); ++i) rank[rest[i]] = nTop + (int)i;
+    }
+    // depth-first pre-order over all usable edges, from state 0, then from whatever is left
+    std::vector<int> pre(N, -1);
+    {
+      std::vector<std::vector<int>> succ(N);
+      for (int j = 0; j < N; ++j) {
+        for (const Pull& q : emitIn[j]) succ[q.src].push_back(j);
+        for (const Pull& q : nullIn[j]) succ[q.src].push_back(j);
+      }
+      int next = 0;
+      std::vector<std::pair<int, size_t>> stack;
+      for (int root = 0; root < N; ++root) {
+        if (pre[root] >= 0) continue;
+        pre[root] = next++;
+        stack.emplace_back(root, 0);
+        while (!stack.empty()) {
+          const int u = stack.back().first;
+          if (stack.back().second < succ[u].size()) {
+            const int v2 = succ[u][stack.back().second++];
+            if (pre[v2] < 0) { pre[v2] = next++; stack.emplace_back(v2, 0); }
+          } else {
+            stack.pop_back();
+          }
+        }
+      }
+    }
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+      if (rank[cls[a]] != rank[cls[b]]) return rank[cls[a]] < rank[cls[b]];
+      return pre[a] < pre[b];
+    });
+  }
   // Lane placement inside each row.  LDS is 64 banks of 4 bytes and a ds_read_b64 is served in
   // two 32-lane halves, so a gather is conflict-free when the 32 source slots of a half fall on
   // 32 different bank pairs, i.e. have different (slot mod 32) = (lane mod 32).  Putting a state

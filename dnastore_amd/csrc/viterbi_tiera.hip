@@ -394,7 +394,10 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
       int xh[D_ > 0 ? D_ : 1];   // xh[i] = x_{pos-i}
       static_for<0, D_>([&](auto ic) { xh[ic.value] = pos - ic.value >= 1 ? seq[pos - ic.value - 1] : 0; });
       // rows 2m, 2m+1 of a thread are neighbours in the lattice: 16-byte loads and stores
-      constexpr int G = 4;                         // rows per load group (two pairs)
+#ifndef DNAS_CGROUP
+#define DNAS_CGROUP 4
+#endif
+      constexpr int G = DNAS_CGROUP;               // rows per load group (even: whole pairs)
       static_for<0, (K + G - 1) / G>([&](auto gc) {
         constexpr int k0 = gc.value * G, k1 = (k0 + G < K) ? k0 + G : K;
         unsigned metaG[G];
