@@ -49,7 +49,8 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
 
   // heavy destinations and LDS cells
   std::vector<char> heavy(N, 0), hasCell(N, 0);
-  for (int j = 0; j < N; ++j) heavy[j] = (int)(emitIn[j].size() + nullIn[j].size()) > kHeavy;
+  // more than kHeavy in-edges, or more than one null in-edge (so that no row needs a second null pull)
+  for (int j = 0; j < N; ++j) heavy[j] = (int)(emitIn[j].size() + nullIn[j].size()) > kHeavy || nullIn[j].size() > 1;
   for (int j = 0; j < N; ++j) {
     if (heavy[j]) hasCell[j] = 1;
     else for (const Pull& q : nullIn[j]) hasCell[q.src] = 1;
@@ -97,14 +98,19 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
   // number of backward edges between classes is found by exhaustive search over the eight
   // largest classes (the rest keep a descending-cost order behind them); inside a class, states
   // follow a depth-first pre-order of the machine so that chains run forward as well.
-  std::vector<int> order(N);
+  std::vector<int> order(N), clsOf(N, 0);
   {
+    // a class = which kinds of pull a state has (emit / null, per score class); states of one
+    // class differ only in how many pulls of each kind they have and are sorted by that below,
+    // so that row boundaries fall between similar shapes
     std::map<Counts, int> classId;
     std::vector<Counts> classes;
     std::vector<int> cls(N), size;
     for (int j = 0; j < N; ++j) {
-      auto it = classId.find(cnt[j]);
-      if (it == classId.end()) { it = classId.emplace(cnt[j], (int)classes.size()).first; classes.push_back(cnt[j]); size.push_back(0); }
+      Counts sig{};
+      for (int q = 0; q < 8; ++q) sig[q] = cnt[j][q] > 0 ? 1 : 0;
+      auto it = classId.find(sig);
+      if (it == classId.end()) { it = classId.emplace(sig, (int)classes.size()).first; classes.push_back(sig); size.push_back(0); }
       cls[j] = it->second;
       ++size[cls[j]];
     }
@@ -161,34 +167,89 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
       }
     }
     std::iota(order.begin(), order.end(), 0);
+    clsOf = cls;
+    auto pulls = [&](int j) { int v = 0; for (int q = 0; q < 8; ++q) v += cnt[j][q]; return v; };
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
       if (rank[cls[a]] != rank[cls[b]]) return rank[cls[a]] < rank[cls[b]];
+      if (pulls(a) != pulls(b)) return pulls(a) > pulls(b);
+      if (cnt[a][8] != cnt[b][8]) return cnt[a][8] > cnt[b][8];
+      if (cnt[a][9] != cnt[b][9]) return cnt[a][9] > cnt[b][9];
       return pre[a] < pre[b];
     });
   }
+  // K*T slots for N states leaves slack.  A row shared by two classes pays for both shapes, so the
+  // slack is spent on starting a class on a fresh row where that lowers the total sweep cost
+  // (emit pulls + 2 x null pulls + pushes + publishes over all rows): greedy, one gap at a time.
+  std::vector<int> posOf(N);          // sorted index -> position in row-major slot space (with gaps)
+  {
+    std::vector<int> boundary;        // sorted indices where a new class starts
+    for (int i = 1; i < N; ++i) if (clsOf[order[i]] != clsOf[order[i - 1]]) boundary.push_back(i);
+    auto layout = [&](const std::vector<char>& gap, std::vector<int>* out) -> long {
+      std::vector<RowShape> rows(K, RowShape{{0, 0, 0, 0}, {0, 0, 0, 0}, 0, 0});
+      int pos = 0;
+      size_t nb = 0;
+      for (int i = 0; i < N; ++i) {
+        if (nb < boundary.size() && boundary[nb] == i) {
+          if (gap[nb] && pos % T) pos += T - pos % T;
+          ++nb;
+        }
+        if (pos >= K * T) return -1;   // does not fit
+        const Counts& c = cnt[order[i]];
+        RowShape& r = rows[pos / T];
+        for (int q = 0; q < 4; ++q) { r.e[q] = std::max(r.e[q], c[q]); r.n[q] = std::max(r.n[q], c[4 + q]); }
+        r.ep = std::max(r.ep, c[8]); r.ec = std::max(r.ec, c[9]);
+        if (out) (*out)[i] = pos;
+        ++pos;
+      }
+      long cost = 0;
+      for (const RowShape& r : rows) cost += r.e[0] + r.e[1] + r.e[2] + r.e[3] + 2 * (r.n[0] + r.n[1] + r.n[2] + r.n[3]) + r.ep + r.ec;
+      return cost;
+    };
+    std::vector<char> gap(boundary.size(), 0);
+    long best = layout(gap, nullptr);
+    for (;;) {
+      int pick = -1;
+      long pickCost = best;
+      for (size_t b = 0; b < boundary.size(); ++b) {
+        if (gap[b]) continue;
+        gap[b] = 1;
+        const long c = layout(gap, nullptr);
+        gap[b] = 0;
+        if (c >= 0 && c < pickCost) { pickCost = c; pick = (int)b; }
+      }
+      if (pick < 0) break;
+      gap[pick] = 1;
+      best = pickCost;
+    }
+    layout(gap, &posOf);
+  }
+
   // Lane placement inside each row.  LDS is 64 banks of 4 bytes and a ds_read_b64 is served in
   // two 32-lane halves, so a gather is conflict-free when the 32 source slots of a half fall on
   // 32 different bank pairs, i.e. have different (slot mod 32) = (lane mod 32).  Putting a state
   // on the lane of its first emit source (or at least on the same lane mod 32) makes the
   // gathers of chain-like machines conflict-free, and keeps a chain inside one thread.
   std::vector<int> laneOf(N, -1), rowOfState(N, -1);
-  for (int i = 0; i < N; ++i) rowOfState[order[i]] = i / T;
-  for (int i = 0; i < N; ++i) laneOf[order[i]] = i % T;          // initial: sort order
+  for (int i = 0; i < N; ++i) rowOfState[order[i]] = posOf[i] / T;
+  for (int i = 0; i < N; ++i) laneOf[order[i]] = posOf[i] % T;   // initial: sort order
+  std::vector<std::vector<int>> rowMembers(K);                    // sorted indices of each row
+  for (int i = 0; i < N; ++i) rowMembers[posOf[i] / T].push_back(i);
   for (int pass = 0; pass < 3; ++pass) {
     for (int k = 0; k < K; ++k) {
-      const int lo = k * T, hi = std::min(N, (k + 1) * T);
-      if (lo >= hi) continue;             // padding row
+      const std::vector<int>& mem = rowMembers[k];
+      if (mem.empty()) continue;          // padding row
+      const int lo = 0, hi = (int)mem.size();
       std::vector<int> lanesFree(T, 1);
       std::vector<int> newLane(hi - lo, -1);
       // exact lane of the primary source first, then same residue, then anything
       for (int i = lo; i < hi; ++i) {
-        const int j = order[i];
+        const int j = order[mem[i]];
         const int src = (!heavy[j] && !emitIn[j].empty()) ? emitIn[j][0].src : -1;
         if (src >= 0 && src != j && lanesFree[laneOf[src]]) { newLane[i - lo] = laneOf[src]; lanesFree[laneOf[src]] = 0; }
       }
       for (int i = lo; i < hi; ++i) {
         if (newLane[i - lo] >= 0) continue;
-        const int j = order[i];
+        const int j = order[mem[i]];
         const int src = (!heavy[j] && !emitIn[j].empty()) ? emitIn[j][0].src : -1;
         if (src >= 0 && src != j) {
           const int r = laneOf[src] % 32;
@@ -203,7 +264,7 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
         newLane[i - lo] = cursor;
         lanesFree[cursor] = 0;
       }
-      for (int i = lo; i < hi; ++i) laneOf[order[i]] = newLane[i - lo];
+      for (int i = lo; i < hi; ++i) laneOf[order[mem[i]]] = newLane[i - lo];
     }
   }
   // two index spaces: LDS index row*T + lane (consecutive lanes -> consecutive bank pairs), and
@@ -247,7 +308,7 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
   long real = 0;
   for (int i = 0; i < N; ++i) {
     const Counts& c = cnt[order[i]];
-    RowShape& r = p.rows[i / T];
+    RowShape& r = p.rows[posOf[i] / T];
     for (int s = 0; s < 4; ++s) { r.e[s] = std::max(r.e[s], c[s]); r.n[s] = std::max(r.n[s], c[4 + s]); }
     r.ep = std::max(r.ep, c[8]); r.ec = std::max(r.ec, c[9]);
     for (int q = 0; q < 10; ++q) real += c[q];
