@@ -91,18 +91,25 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
     c[9] = hasCell[j] ? 1 : 0;
     cnt[j] = c;
   }
-  // Rows come out (nearly) homogeneous when identical count vectors ("classes") sit together.
-  // The ORDER of the classes decides how far a value travels inside one sweep: rows run in
-  // order, so an edge from an earlier row to a later one is relaxed in the same sweep while an
-  // edge pointing back costs another sweep.  The classes are few: the order that minimises the
-  // number of backward edges between classes is found by exhaustive search over the eight
-  // largest classes (the rest keep a descending-cost order behind them); inside a class, states
-  // follow a depth-first pre-order of the machine so that chains run forward as well.
-  std::vector<int> order(N), clsOf(N, 0);
+  // ---- which state goes to which row ------------------------------------------------------
+  // Two things decide what a sweep costs.  (1) Row shapes: a row pays, for all T threads, the
+  // largest pull list any of its states has, so rows should hold states of one kind ("class":
+  // which kinds of pull a state has).  (2) The ORDER in which rows are evaluated: a thread walks
+  // its rows 0..K-1, so a value crosses an edge within the same sweep when the destination sits
+  // in a LATER row than the source, and needs another sweep otherwise.  The in-column recursion
+  // runs along the machine's chains (deletions follow the emit edges), so the number of sweeps
+  // to the fixpoint is about (how far a value travels) x (share of backward edges on its way).
+  //
+  // The rows are therefore laid out as a "program" of shapes that follows the machine's cycle:
+  // classes in the order that minimises backward edges between them (exhaustive search over the
+  // eight largest), every class on rows of its own where the slack allows, shapes ascending
+  // inside a class; then the states are dealt onto that program along a depth-first walk of the
+  // machine, each state into the first row behind its parent's row whose shape admits it -- a
+  // chain runs down the rows of one sweep instead of along one row.  The candidates (which class
+  // boundaries are padded to a fresh row) are scored by  (LDS reads per sweep) x (sweeps, as
+  // the largest number of backward edges on any walk of kWalk edges)  and the best one is kept.
+  std::vector<int> rowOfState(N, -1);
   {
-    // a class = which kinds of pull a state has (emit / null, per score class); states of one
-    // class differ only in how many pulls of each kind they have and are sorted by that below,
-    // so that row boundaries fall between similar shapes
     std::map<Counts, int> classId;
     std::vector<Counts> classes;
     std::vector<int> cls(N), size;
@@ -116,9 +123,10 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
     }
     const int nC = (int)classes.size();
     std::vector<std::vector<long>> w(nC, std::vector<long>(nC, 0));   // edges class a -> class b
+    std::vector<int> eSrc, eDst;
     for (int j = 0; j < N; ++j) {
-      for (const Pull& q : emitIn[j]) ++w[cls[q.src]][cls[j]];
-      for (const Pull& q : nullIn[j]) ++w[cls[q.src]][cls[j]];
+      for (const Pull& q : emitIn[j]) { ++w[cls[q.src]][cls[j]]; eSrc.push_back(q.src); eDst.push_back(j); }
+      for (const Pull& q : nullIn[j]) { ++w[cls[q.src]][cls[j]]; eSrc.push_back(q.src); eDst.push_back(j); }
     }
     std::vector<int> bySize(nC);
     std::iota(bySize.begin(), bySize.end(), 0);
@@ -142,129 +150,234 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
       for (size_t i = 0; i < rest.size(); ++i) rank[rest[i]] = nTop + (int)i;
     }
     // depth-first pre-order over all usable edges, from state 0, then from whatever is left
-    std::vector<int> pre(N, -1);
+    std::vector<int> pre(N, -1), parent(N, -1), walk;
+    walk.reserve(N);
     {
       std::vector<std::vector<int>> succ(N);
-      for (int j = 0; j < N; ++j) {
-        for (const Pull& q : emitIn[j]) succ[q.src].push_back(j);
-        for (const Pull& q : nullIn[j]) succ[q.src].push_back(j);
-      }
+      for (size_t e = 0; e < eSrc.size(); ++e) succ[eSrc[e]].push_back(eDst[e]);
       int next = 0;
       std::vector<std::pair<int, size_t>> stack;
       for (int root = 0; root < N; ++root) {
         if (pre[root] >= 0) continue;
         pre[root] = next++;
+        walk.push_back(root);
         stack.emplace_back(root, 0);
         while (!stack.empty()) {
           const int u = stack.back().first;
           if (stack.back().second < succ[u].size()) {
             const int v2 = succ[u][stack.back().second++];
-            if (pre[v2] < 0) { pre[v2] = next++; stack.emplace_back(v2, 0); }
+            if (pre[v2] < 0) { pre[v2] = next++; parent[v2] = u; walk.push_back(v2); stack.emplace_back(v2, 0); }
           } else {
             stack.pop_back();
           }
         }
       }
     }
+    // push / publish entries cost a register, not a read.  Where a class needs them often they
+    // are allowed on all of its rows (a chain of such states must not be forced backwards);
+    // where they are rare they sort to the end of their group and land on few rows.
+    std::vector<std::array<char, 2>> common(nC, std::array<char, 2>{0, 0});
+    for (int c = 0; c < nC; ++c)
+      for (int q = 0; q < 2; ++q) {
+        long have = 0;
+        for (int j = 0; j < N; ++j) if (cls[j] == c && cnt[j][8 + q] > 0) ++have;
+        common[c][q] = have * 4 >= size[c];
+      }
+    std::vector<int> order(N);
     std::iota(order.begin(), order.end(), 0);
-    clsOf = cls;
     auto pulls = [&](int j) { int v = 0; for (int q = 0; q < 8; ++q) v += cnt[j][q]; return v; };
+    auto rare = [&](int j, int q) { return common[cls[j]][q] ? 0 : cnt[j][8 + q]; };
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
       if (rank[cls[a]] != rank[cls[b]]) return rank[cls[a]] < rank[cls[b]];
-      if (pulls(a) != pulls(b)) return pulls(a) > pulls(b);
-      if (cnt[a][8] != cnt[b][8]) return cnt[a][8] > cnt[b][8];
-      if (cnt[a][9] != cnt[b][9]) return cnt[a][9] > cnt[b][9];
+      if (pulls(a) != pulls(b)) return pulls(a) < pulls(b);
+      if (rare(a, 0) != rare(b, 0)) return rare(a, 0) < rare(b, 0);
+      if (rare(a, 1) != rare(b, 1)) return rare(a, 1) < rare(b, 1);
       return pre[a] < pre[b];
     });
-  }
-  // K*T slots for N states leaves slack.  A row shared by two classes pays for both shapes, so the
-  // slack is spent on starting a class on a fresh row where that lowers the total sweep cost
-  // (emit pulls + 2 x null pulls + pushes + publishes over all rows): greedy, one gap at a time.
-  std::vector<int> posOf(N);          // sorted index -> position in row-major slot space (with gaps)
-  {
     std::vector<int> boundary;        // sorted indices where a new class starts
-    for (int i = 1; i < N; ++i) if (clsOf[order[i]] != clsOf[order[i - 1]]) boundary.push_back(i);
-    auto layout = [&](const std::vector<char>& gap, std::vector<int>* out) -> long {
-      std::vector<RowShape> rows(K, RowShape{{0, 0, 0, 0}, {0, 0, 0, 0}, 0, 0});
-      int pos = 0;
+    for (int i = 1; i < N; ++i) if (cls[order[i]] != cls[order[i - 1]]) boundary.push_back(i);
+
+    // the row program of one candidate: shapes of the row-major layout with the chosen gaps
+    auto program = [&](const std::vector<char>& gap, std::vector<Counts>* caps, std::vector<int>* rows) -> bool {
+      caps->assign(K, Counts{});
+      int pos = 0, last = 0;
       size_t nb = 0;
       for (int i = 0; i < N; ++i) {
         if (nb < boundary.size() && boundary[nb] == i) {
           if (gap[nb] && pos % T) pos += T - pos % T;
           ++nb;
         }
-        if (pos >= K * T) return -1;   // does not fit
-        const Counts& c = cnt[order[i]];
-        RowShape& r = rows[pos / T];
-        for (int q = 0; q < 4; ++q) { r.e[q] = std::max(r.e[q], c[q]); r.n[q] = std::max(r.n[q], c[4 + q]); }
-        r.ep = std::max(r.ep, c[8]); r.ec = std::max(r.ec, c[9]);
-        if (out) (*out)[i] = pos;
+        if (pos >= K * T) return false;
+        const int j = order[i];
+        Counts& r = (*caps)[pos / T];
+        for (int q = 0; q < 10; ++q) r[q] = std::max(r[q], cnt[j][q]);
+        for (int q = 0; q < 2; ++q) if (common[cls[j]][q]) r[8 + q] = 1;
+        (*rows)[j] = last = pos / T;
         ++pos;
       }
-      long cost = 0;
-      for (const RowShape& r : rows) cost += r.e[0] + r.e[1] + r.e[2] + r.e[3] + 2 * (r.n[0] + r.n[1] + r.n[2] + r.n[3]) + r.ep + r.ec;
-      return cost;
+      for (int k = last + 1; k < K; ++k) (*caps)[k] = (*caps)[last];   // spare rows repeat the last shape
+      return true;
     };
-    std::vector<char> gap(boundary.size(), 0);
-    long best = layout(gap, nullptr);
-    for (;;) {
-      int pick = -1;
-      long pickCost = best;
-      for (size_t b = 0; b < boundary.size(); ++b) {
-        if (gap[b]) continue;
-        gap[b] = 1;
-        const long c = layout(gap, nullptr);
-        gap[b] = 0;
-        if (c >= 0 && c < pickCost) { pickCost = c; pick = (int)b; }
-      }
-      if (pick < 0) break;
-      gap[pick] = 1;
-      best = pickCost;
+    // deal the states onto a program along the depth-first walk
+    std::map<Counts, int> typeId;
+    std::vector<int> typeOf(N);
+    std::vector<Counts> types;
+    for (int j = 0; j < N; ++j) {
+      auto it = typeId.find(cnt[j]);
+      if (it == typeId.end()) { it = typeId.emplace(cnt[j], (int)types.size()).first; types.push_back(cnt[j]); }
+      typeOf[j] = it->second;
     }
-    layout(gap, &posOf);
+    auto deal = [&](const std::vector<Counts>& caps, std::vector<int>* rows) -> bool {
+      std::vector<unsigned> admits(types.size(), 0);
+      for (size_t t = 0; t < types.size(); ++t)
+        for (int k = 0; k < K; ++k) {
+          bool ok = true;
+          for (int q = 0; q < 10; ++q) ok = ok && types[t][q] <= caps[k][q];
+          if (ok) admits[t] |= 1u << k;
+        }
+      std::vector<std::vector<int>> members(K);
+      unsigned freeRows = (1u << K) - 1u;
+      rows->assign(N, -1);
+      auto put = [&](int j, int k) {
+        (*rows)[j] = k;
+        members[k].push_back(j);
+        if ((int)members[k].size() == T) freeRows &= ~(1u << k);
+      };
+      auto firstBehind = [&](unsigned avail, int j) {
+        const int par = parent[j];
+        const int start = (par >= 0 && (*rows)[par] >= 0) ? (*rows)[par] + 1 : 0;
+        const unsigned fw = start < 32 ? avail & ~((1u << start) - 1u) : 0u;
+        return __builtin_ctz(fw ? fw : avail);
+      };
+      for (int j : walk) {
+        unsigned avail = admits[typeOf[j]] & freeRows;
+        if (!avail) {
+          // every row that admits j is full: move a more flexible resident of one of them elsewhere
+          bool moved = false;
+          for (int k = 0; k < K && !moved; ++k) {
+            if (!(admits[typeOf[j]] >> k & 1u)) continue;
+            for (size_t m = 0; m < members[k].size(); ++m) {
+              const int i = members[k][m];
+              const unsigned alt = admits[typeOf[i]] & freeRows;
+              if (!alt) continue;
+              members[k].erase(members[k].begin() + (long)m);
+              freeRows |= 1u << k;
+              put(i, firstBehind(alt, i));
+              moved = true;
+              break;
+            }
+          }
+          if (!moved) return false;
+          avail = admits[typeOf[j]] & freeRows;
+        }
+        put(j, firstBehind(avail, j));
+      }
+      return true;
+    };
+    // score: gathers per sweep (emit pulls + 2 per null pull) x estimated sweeps
+    constexpr int kWalk = 30;
+    auto score = [&](const std::vector<int>& rows, long* readsOut, int* backOut) -> double {
+      std::vector<Counts> shape(K, Counts{});
+      for (int j = 0; j < N; ++j)
+        for (int q = 0; q < 10; ++q) shape[rows[j]][q] = std::max(shape[rows[j]][q], cnt[j][q]);
+      long reads = 0, entries = 0;
+      for (const Counts& r : shape) {
+        reads += r[0] + r[1] + r[2] + r[3] + 2 * (r[4] + r[5] + r[6] + r[7]);
+        for (int q = 0; q < 10; ++q) entries += r[q];
+      }
+      std::vector<int> f(N, 0), g(N);
+      for (int h = 0; h < kWalk; ++h) {
+        std::fill(g.begin(), g.end(), 0);
+        for (size_t e = 0; e < eSrc.size(); ++e) {
+          const int v = f[eSrc[e]] + (rows[eDst[e]] <= rows[eSrc[e]] ? 1 : 0);
+          if (v > g[eDst[e]]) g[eDst[e]] = v;
+        }
+        f.swap(g);
+      }
+      int back = 0;
+      for (int v : f) back = std::max(back, v);
+      if (readsOut) *readsOut = reads;
+      if (backOut) *backOut = back;
+      if (entries > 56) return 1e30;
+      return (double)(reads + 10) * (double)(back + 1);
+    };
+    const int nGap = (int)std::min<size_t>(boundary.size(), 10);   // boundaries between the first classes; later ones stay packed
+    double bestScore = 1e31;
+    std::vector<Counts> caps;
+    std::vector<int> rowsMajor(N), rowsDealt;
+    for (unsigned bits = 0; bits < (1u << nGap); ++bits) {
+      std::vector<char> gap(boundary.size(), 0);
+      for (int b = 0; b < nGap; ++b) gap[b] = (bits >> b) & 1u;
+      if (!program(gap, &caps, &rowsMajor)) continue;
+      const std::vector<int>* cand = &rowsMajor;
+      if (deal(caps, &rowsDealt)) cand = &rowsDealt;
+      long reads = 0;
+      int back = 0;
+      const double sc = score(*cand, &reads, &back);
+      if (sc < bestScore) { bestScore = sc; rowOfState = *cand; p.sweepReads = (int)reads; p.backEdgesOnWalk = back; }
+    }
+    if (bestScore >= 1e30) return no("row shapes need more than 56 entry registers per thread");
   }
 
-  // Lane placement inside each row.  LDS is 64 banks of 4 bytes and a ds_read_b64 is served in
-  // two 32-lane halves, so a gather is conflict-free when the 32 source slots of a half fall on
-  // 32 different bank pairs, i.e. have different (slot mod 32) = (lane mod 32).  Putting a state
-  // on the lane of its first emit source (or at least on the same lane mod 32) makes the
-  // gathers of chain-like machines conflict-free, and keeps a chain inside one thread.
-  std::vector<int> laneOf(N, -1), rowOfState(N, -1);
-  for (int i = 0; i < N; ++i) rowOfState[order[i]] = posOf[i] / T;
-  for (int i = 0; i < N; ++i) laneOf[order[i]] = posOf[i] % T;   // initial: sort order
-  std::vector<std::vector<int>> rowMembers(K);                    // sorted indices of each row
-  for (int i = 0; i < N; ++i) rowMembers[posOf[i] / T].push_back(i);
-  for (int pass = 0; pass < 3; ++pass) {
+  // Lane placement inside each row.  Two goals.  (1) The waves of a work-group sweep without a
+  // barrier and drift apart, so an edge into a later row is only CERTAIN to be relaxed in the
+  // same sweep when source and destination belong to the same wave (a wave runs its rows in
+  // order): a state goes to the wave of its "lead" -- the source in an earlier row it hangs on.
+  // (2) LDS is 64 banks of 4 bytes and a ds_read_b64 is served in two 32-lane halves, so a
+  // gather is conflict-free when the 32 source slots of a half fall on 32 different bank pairs,
+  // i.e. have different (lane mod 32): best is the lead's own lane (the chain stays inside one
+  // thread), then the other lane of that wave with the same residue, then any lane of the wave
+  // whose half does not yet read that bank pair, then the same residue in another wave.
+  std::vector<int> laneOf(N, -1);
+  std::vector<std::vector<int>> rowMembers(K);                    // states of each row
+  for (int j = 0; j < N; ++j) { laneOf[j] = (int)rowMembers[rowOfState[j]].size(); rowMembers[rowOfState[j]].push_back(j); }
+  auto leadOf = [&](int j) {
+    // first source in an earlier row (emit edges first), else the first source at all
+    int any = -1;
+    if (heavy[j]) return -1;
+    for (const Pull& q : emitIn[j]) { if (q.src == j) continue; if (rowOfState[q.src] < rowOfState[j]) return q.src; if (any < 0) any = q.src; }
+    for (const Pull& q : nullIn[j]) { if (q.src == j) continue; if (rowOfState[q.src] < rowOfState[j]) return q.src; if (any < 0) any = q.src; }
+    return any;
+  };
+  for (int pass = 0; pass < 2; ++pass) {
     for (int k = 0; k < K; ++k) {
       const std::vector<int>& mem = rowMembers[k];
       if (mem.empty()) continue;          // padding row
-      const int lo = 0, hi = (int)mem.size();
-      std::vector<int> lanesFree(T, 1);
-      std::vector<int> newLane(hi - lo, -1);
-      // exact lane of the primary source first, then same residue, then anything
-      for (int i = lo; i < hi; ++i) {
-        const int j = order[mem[i]];
-        const int src = (!heavy[j] && !emitIn[j].empty()) ? emitIn[j][0].src : -1;
-        if (src >= 0 && src != j && lanesFree[laneOf[src]]) { newLane[i - lo] = laneOf[src]; lanesFree[laneOf[src]] = 0; }
+      const int n = (int)mem.size();
+      std::vector<char> lanesFree(T, 1);
+      std::vector<int> newLane(n, -1), lead(n, -1);
+      std::vector<std::array<unsigned char, 32>> bankUse(T / 32);   // per 32-lane half: gathers per bank pair
+      for (auto& h : bankUse) h.fill(0);
+      auto take = [&](int i, int t) { newLane[i] = t; lanesFree[t] = 0; if (lead[i] >= 0) ++bankUse[t / 32][laneOf[lead[i]] % 32]; };
+      for (int i = 0; i < n; ++i) lead[i] = leadOf(mem[i]);
+      for (int i = 0; i < n; ++i)          // the lead's own lane
+        if (lead[i] >= 0 && lanesFree[laneOf[lead[i]]]) take(i, laneOf[lead[i]]);
+      for (int i = 0; i < n; ++i) {        // same wave, same residue
+        if (newLane[i] >= 0 || lead[i] < 0) continue;
+        const int t = laneOf[lead[i]] ^ 32;
+        if (lanesFree[t]) take(i, t);
       }
-      for (int i = lo; i < hi; ++i) {
-        if (newLane[i - lo] >= 0) continue;
-        const int j = order[mem[i]];
-        const int src = (!heavy[j] && !emitIn[j].empty()) ? emitIn[j][0].src : -1;
-        if (src >= 0 && src != j) {
-          const int r = laneOf[src] % 32;
-          for (int t = r; t < T; t += 32)
-            if (lanesFree[t]) { newLane[i - lo] = t; lanesFree[t] = 0; break; }
-        }
+      for (int i = 0; i < n; ++i) {        // same wave, a half that does not read this bank pair yet
+        if (newLane[i] >= 0 || lead[i] < 0) continue;
+        const int w0 = laneOf[lead[i]] & ~63, r = laneOf[lead[i]] % 32;
+        int bestT = -1, bestUse = 1 << 30;
+        for (int t = w0; t < w0 + 64; ++t)
+          if (lanesFree[t] && bankUse[t / 32][r] < bestUse) { bestUse = bankUse[t / 32][r]; bestT = t; }
+        if (bestT >= 0) take(i, bestT);
+      }
+      for (int i = 0; i < n; ++i) {        // another wave, same residue
+        if (newLane[i] >= 0 || lead[i] < 0) continue;
+        const int r = laneOf[lead[i]] % 32;
+        for (int t = r; t < T; t += 32)
+          if (lanesFree[t]) { take(i, t); break; }
       }
       int cursor = 0;
-      for (int i = lo; i < hi; ++i) {
-        if (newLane[i - lo] >= 0) continue;
+      for (int i = 0; i < n; ++i) {
+        if (newLane[i] >= 0) continue;
         while (!lanesFree[cursor]) ++cursor;
-        newLane[i - lo] = cursor;
-        lanesFree[cursor] = 0;
+        take(i, cursor);
       }
-      for (int i = lo; i < hi; ++i) laneOf[order[mem[i]]] = newLane[i - lo];
+      for (int i = 0; i < n; ++i) laneOf[mem[i]] = newLane[i];
     }
   }
   // two index spaces: LDS index row*T + lane (consecutive lanes -> consecutive bank pairs), and
@@ -306,9 +419,9 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
 
   p.rows.assign(K, RowShape{{0, 0, 0, 0}, {0, 0, 0, 0}, 0, 0});
   long real = 0;
-  for (int i = 0; i < N; ++i) {
-    const Counts& c = cnt[order[i]];
-    RowShape& r = p.rows[posOf[i] / T];
+  for (int j = 0; j < N; ++j) {
+    const Counts& c = cnt[j];
+    RowShape& r = p.rows[rowOfState[j]];
     for (int s = 0; s < 4; ++s) { r.e[s] = std::max(r.e[s], c[s]); r.n[s] = std::max(r.n[s], c[4 + s]); }
     r.ep = std::max(r.ep, c[8]); r.ec = std::max(r.ec, c[9]);
     for (int q = 0; q < 10; ++q) real += c[q];

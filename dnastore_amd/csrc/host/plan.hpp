@@ -38,6 +38,8 @@ struct TierAPlan {
   double score[4] = {0, 0, 0, 0};
   size_t ldsBytes = 0;
   double fillRatio = 0;           // real entries / padded entries
+  int sweepReads = 0;             // LDS gathers per thread and sweep (emit pulls + 2 per null pull)
+  int backEdgesOnWalk = 0;        // most backward edges (destination row <= source row) on any walk of 30 edges
   long ldsCycles = 0, ldsCyclesIdeal = 0;   // modelled LDS cycles of one sweep's gathers (with / without bank conflicts)
 };
 

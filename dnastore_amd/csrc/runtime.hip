@@ -480,7 +480,8 @@ extern "C" int dnas_tiera_precompile(const dnas_flat_model* fm, char* note, size
     } else {
       (void)dnas::jitCompile(dnas::libraryDir() + "/csrc/viterbi_tiera.hip", p.defines, p.key);
       msg = "tier A: " + p.key + " lds=" + std::to_string(p.ldsBytes) + " fill=" + std::to_string(p.fillRatio) + " ldsCycles=" +
-            std::to_string(p.ldsCycles) + "/" + std::to_string(p.ldsCyclesIdeal);
+            std::to_string(p.ldsCycles) + "/" + std::to_string(p.ldsCyclesIdeal) + " reads=" + std::to_string(p.sweepReads) +
+            " entries=" + std::to_string(p.nEntries) + " back=" + std::to_string(p.backEdgesOnWalk);
     }
     if (note && note_cap) { strncpy(note, msg.c_str(), note_cap - 1); note[note_cap - 1] = 0; }
     return DNAS_OK;

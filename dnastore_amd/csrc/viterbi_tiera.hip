@@ -130,6 +130,10 @@ __device__ __forceinline__ unsigned opaque(unsigned v) {
 
 constexpr double kNegInf = -__builtin_huge_val();
 
+#ifndef DNAS_PIPE
+#define DNAS_PIPE 1
+#endif
+
 extern "C" __global__ void __launch_bounds__(DNAS_T)
 viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntries][T]
                    const unsigned* __restrict__ metaTab,                // [K][T]: mdl | ctx<<4 | flags
@@ -291,15 +295,19 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
     // issued before row k is evaluated (software pipeline).
     {
       constexpr int NW = DNAS_T / 64;
+      // DNAS_PIPE 1: the gathers of a row are issued when its turn comes, so a value crosses every
+      // forward edge (source row < destination row) within one sweep -- the plan lays chains out
+      // along ascending rows.  2: one row of read-ahead (a hop then needs two rows of distance).
+      constexpr int PIPE = DNAS_PIPE;
       const int wv = tid >> 6, ln = tid & 63;
       for (;;) {
         asm volatile("" ::: "memory");   // other waves write LDS between sweeps: reload everything
         const unsigned e0 = __hip_atomic_load(epochL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (ln == 0) __hip_atomic_store(&idleL[wv], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         int changed = 0;
-        double buf[2][kMaxRowVals > 0 ? kMaxRowVals : 1];
+        double buf[PIPE][kMaxRowVals > 0 ? kMaxRowVals : 1];
         auto issue = [&](auto kc) {
-          constexpr int k = kc.value, o = rowOffset(k), b = k & 1;
+          constexpr int k = kc.value, o = rowOffset(k), b = k % PIPE;
 #ifdef DNAS_DIAG_NO_LDS_READS   // timing experiment: what do the sweeps cost without their gathers
           static_for<0, rowEE(k) + 2 * rowEN(k)>([&](auto ec) { buf[b][ec.value] = __uint_as_float(E[o]) > 3.f ? 1.0 : kNegInf; });
 #else
@@ -311,10 +319,11 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
           });
 #endif
         };
-        issue(IntC<0>{});
+        if constexpr (PIPE == 2) issue(IntC<0>{});
         static_for<0, K>([&](auto kc) {
-          constexpr int k = kc.value, o = rowOffset(k), b = k & 1;
-          if constexpr (k + 1 < K) issue(IntC<k + 1>{});
+          constexpr int k = kc.value, o = rowOffset(k), b = k % PIPE;
+          if constexpr (PIPE == 1) issue(kc);
+          else if constexpr (k + 1 < K) issue(IntC<k + 1>{});
           double s = S[k], d = Dv[k];
           static_for<0, rowEE(k)>([&](auto ec) {
             constexpr int cls = emitClass(k, ec.value);
