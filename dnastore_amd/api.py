@@ -152,6 +152,19 @@ class FlatModel:
         _l.check(_l.lib().dnas_tiera_plan_slots(self.view, lds.ctypes.data, lat.ctypes.data, ctypes.addressof(t), ctypes.addressof(k)))
         return lds, lat, t.value, k.value
 
+    def plan_tables(self):
+        """Tier-A tables as the fill kernel receives them: (row_shapes int32[K][2], entries uint32[nEntries][T],
+        meta uint32[K][T], n_s_rows)."""
+        _, _, t, k = self.plan_slots()
+        ne, ns = ctypes.c_int32(), ctypes.c_int32()
+        _l.check(_l.lib().dnas_tiera_plan_tables(self.view, None, None, 0, None, ctypes.addressof(ne), ctypes.addressof(ns)))
+        shapes = np.zeros((k, 2), dtype=np.int32)
+        ent = np.zeros((ne.value, t), dtype=np.uint32)
+        meta = np.zeros((k, t), dtype=np.uint32)
+        _l.check(_l.lib().dnas_tiera_plan_tables(self.view, shapes.ctypes.data, ent.ctypes.data, ent.size, meta.ctypes.data,
+                                                 ctypes.addressof(ne), ctypes.addressof(ns)))
+        return shapes, ent, meta, ns.value
+
     def precompile(self):
         """JIT-specialise the tier-A fill kernel for this machine into dnastore_amd/kcache (no GPU needed)."""
         buf = ctypes.create_string_buffer(1024)

@@ -1,15 +1,16 @@
 // Tier-A schedule: how one machine's states and edges are laid over the 1024 threads of
 // the register/LDS-resident fill kernel (csrc/viterbi_tiera.hip).  Pure host code.
 //
-//  * every state gets a slot = row*T + thread; rows are processed in order inside a sweep
-//  * a state's in-edges become per-thread 32-bit entries (kept in registers by the kernel):
-//      emit pull  D(j) >= X(src)+score                      (viterbi.cpp:123-125, pulled)
-//      null pull  D(j) >= DN(src)+score, S(j) >= SN(src)+score   (viterbi.cpp:137-151)
-//      push       in-edges of "heavy" destinations (in-degree > kHeavy) are executed by the
-//                 source's thread as LDS atomic max into the destination's cell
-//      publish    states that own an LDS cell (null-edge sources, heavy destinations)
-//  * states are sorted so that each row is (nearly) homogeneous in entry counts; the per-row
-//    maxima form the row shape that the kernel is compiled for.
+//  * every state gets a place = (row, thread); a thread evaluates its rows in order inside a
+//    sweep, and keeps the S and D cells of its states in registers
+//  * every state owns an LDS accumulator DC[row*T + thread] that its in-edges are pushed into
+//    (ds_max_f64), and -- if it has null in-edges -- a second one, SC, in a stripe of T cells
+//    that its row shares ("S rows")
+//  * a state's OUT-edges become per-thread 32-bit entries (kept in registers by the kernel):
+//      emit edge  D(dst) >= max(D+delExtend, S+delOpen) + score        (viterbi.cpp:123-125)
+//                 and, between columns, S(dst) >= S + score + noGap + sub   (viterbi.cpp:92-95)
+//      null edge  D(dst) >= D + score,  S(dst) >= S + score             (viterbi.cpp:137-151)
+//  * the per-row maxima (out-edges, needs an S cell) form the row shape the kernel is compiled for
 #pragma once
 #include <cstdint>
 #include <string>
@@ -19,28 +20,26 @@
 
 namespace dnas {
 
-// per row: emit pulls / null pulls by score class (class 0 = score 0.0), pushes, publishes
-struct RowShape { int e[4], n[4], ep, ec; };
+// per row: out-edge entries per state, and the row's S stripe (-1: no state of the row has null in-edges)
+struct RowShape { int nOut, sIdx; };
 
 struct TierAPlan {
   bool ok = false;
   std::string whyNot;
-  int T = 1024, K = 0, D = 0, N = 0, NS = 0, C = 0, xDummy = 0, nEntries = 0;
+  int T = 1024, K = 0, D = 0, N = 0, NS = 0, nSRows = 0, nClasses = 1, nEntries = 0;
   std::vector<RowShape> rows;
   std::string defines;            // "-DDNAS_T=.. -DDNAS_K=.. -DDNAS_D=.. -DDNAS_ROWS=.." joined by '\n'
   std::string key;                // cache key of the specialisation
-  std::vector<int32_t> slotOf;    // [N]  state -> slot
-  std::vector<int32_t> stateOf;   // [NS] LDS index (row*T + lane) -> state or -1
-  std::vector<uint32_t> entTab;   // [nEntries][T]
+  std::vector<int32_t> slotOf;    // [N]  state -> lattice slot (row/2)*2T + 2*thread + (row&1)
+  std::vector<int32_t> stateOf;   // [NS] LDS index (row*T + thread) -> state or -1
+  std::vector<uint32_t> entTab;   // [nEntries][T]  out-edges, see viterbi_tiera.hip
   std::vector<uint32_t> metaTab;  // [K][T]  mdl | ctx<<4 | flags
-  std::vector<uint32_t> baseTab;  // [nBaseWords][T]  emitted base of the thread's i-th emit pull, 2 bits each, 16 per word
-  int nBaseWords = 1;
   double score[4] = {0, 0, 0, 0};
   size_t ldsBytes = 0;
   double fillRatio = 0;           // real entries / padded entries
-  int sweepReads = 0;             // LDS gathers per thread and sweep (emit pulls + 2 per null pull)
+  int sweepReads = 0;             // LDS reads per thread and sweep (own cells)
   int backEdgesOnWalk = 0;        // most backward edges (destination row <= source row) on any walk of 30 edges
-  long ldsCycles = 0, ldsCyclesIdeal = 0;   // modelled LDS cycles of one sweep's gathers (with / without bank conflicts)
+  double sameWave = 0;            // share of forward edges whose ends sit in the same wave
 };
 
 constexpr int kTierAThreads = 1024;

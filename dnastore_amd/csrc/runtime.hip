@@ -41,7 +41,6 @@ struct TierALaunch {
   TierAArgs a;
   const unsigned* entTab;
   const unsigned* metaTab;
-  const unsigned* baseTab;
   const uint8_t* bases;
   const uint64_t* readOff;
   const int32_t* batchRead;
@@ -59,7 +58,7 @@ struct dnas_model {
   hipModule_t module = nullptr;
   hipFunction_t fillA = nullptr;
   TierAArgs argsA{};
-  unsigned *dEntTab = nullptr, *dMetaTab = nullptr, *dBaseTab = nullptr;
+  unsigned *dEntTab = nullptr, *dMetaTab = nullptr;
   int32_t* dSlotOf = nullptr;
   hipStream_t stream = nullptr;     // fill kernels
   hipStream_t stream2 = nullptr;    // traceback kernels (batch i traces back while batch i+1 fills)
@@ -180,8 +179,6 @@ extern "C" int dnas_model_create(const dnas_flat_model* fm, int device_id, size_
           if (hipMalloc((void**)&m->dEntTab, p.entTab.size() * 4) != hipSuccess ||
               hipMalloc((void**)&m->dMetaTab, p.metaTab.size() * 4) != hipSuccess ||
               hipMalloc((void**)&m->dSlotOf, p.slotOf.size() * 4) != hipSuccess ||
-              hipMalloc((void**)&m->dBaseTab, p.baseTab.size() * 4) != hipSuccess ||
-              hipMemcpy(m->dBaseTab, p.baseTab.data(), p.baseTab.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
               hipMemcpy(m->dEntTab, p.entTab.data(), p.entTab.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
               hipMemcpy(m->dMetaTab, p.metaTab.data(), p.metaTab.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
               hipMemcpy(m->dSlotOf, p.slotOf.data(), p.slotOf.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
@@ -227,7 +224,6 @@ extern "C" void dnas_model_destroy(dnas_model* m) {
   if (m->keepBases) (void)hipFree(m->keepBases);
   if (m->dEntTab) (void)hipFree(m->dEntTab);
   if (m->dMetaTab) (void)hipFree(m->dMetaTab);
-  if (m->dBaseTab) (void)hipFree(m->dBaseTab);
   if (m->dSlotOf) (void)hipFree(m->dSlotOf);
   if (m->module) (void)hipModuleUnload(m->module);
   if (m->dBatchRead) (void)hipFree(m->dBatchRead);
@@ -358,7 +354,7 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
     if (b >= 2) HIP_TRY(hipStreamWaitEvent(m->stream, m->sync[2 * (b - 2) + 1], 0));
     HIP_TRY(hipEventRecord(m->events[4 * b], m->stream));
     if (m->tier == 1) {
-      TierALaunch la{m->argsA, m->dEntTab, m->dMetaTab, m->dBaseTab, d_bases, m->dReadOff, m->dBatchRead + s, m->dSlotOff + s,
+      TierALaunch la{m->argsA, m->dEntTab, m->dMetaTab, d_bases, m->dReadOff, m->dBatchRead + s, m->dSlotOff + s,
                      m->arena, d_out_loglike, m->dRounds};
       size_t laSize = sizeof la;
       void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &la, HIP_LAUNCH_PARAM_BUFFER_SIZE, &laSize, HIP_LAUNCH_PARAM_END};
@@ -468,6 +464,29 @@ extern "C" int dnas_model_read_lattice(dnas_model* m, int64_t slot, int64_t len,
   return DNAS_OK;
 }
 
+// Analysis / test aid: the tier-A tables of a machine exactly as the kernel receives them (no GPU
+// needed): row shapes [K][2] = {out-edge entries, S stripe or -1}, the entry table [n_entries][T]
+// and the meta table [K][T].  Either output may be NULL; *n_entries / *n_s_rows are always set.
+extern "C" int dnas_tiera_plan_tables(const dnas_flat_model* fm, int32_t* row_shapes, uint32_t* entries, size_t entries_cap,
+                                      uint32_t* meta, int32_t* n_entries, int32_t* n_s_rows) {
+  if (!fm) return dnas::fail(DNAS_E_INVALID, "null argument");
+  try {
+    const dnas::TierAPlan p = dnas::buildTierAPlan(*fm);
+    if (!p.ok) return dnas::fail(DNAS_E_UNSUPPORTED, p.whyNot);
+    if (n_entries) *n_entries = p.nEntries;
+    if (n_s_rows) *n_s_rows = p.nSRows;
+    if (row_shapes) for (int k = 0; k < p.K; ++k) { row_shapes[2 * k] = p.rows[k].nOut; row_shapes[2 * k + 1] = p.rows[k].sIdx; }
+    if (entries) {
+      if (entries_cap < p.entTab.size()) return dnas::fail(DNAS_E_INVALID, "entry buffer too small");
+      memcpy(entries, p.entTab.data(), p.entTab.size() * sizeof(uint32_t));
+    }
+    if (meta) memcpy(meta, p.metaTab.data(), p.metaTab.size() * sizeof(uint32_t));
+    return DNAS_OK;
+  } catch (const std::exception& e) {
+    return dnas::fail(DNAS_E_DEVICE, e.what());
+  }
+}
+
 // Build-time helper: specialise and compile the tier-A kernel for a machine without touching
 // a GPU (fills dnastore_amd/kcache so that the GPU box finds the code object ready).
 extern "C" int dnas_tiera_precompile(const dnas_flat_model* fm, char* note, size_t note_cap) {
@@ -479,9 +498,9 @@ extern "C" int dnas_tiera_precompile(const dnas_flat_model* fm, char* note, size
       msg = "tier B: " + p.whyNot;
     } else {
       (void)dnas::jitCompile(dnas::libraryDir() + "/csrc/viterbi_tiera.hip", p.defines, p.key);
-      msg = "tier A: " + p.key + " lds=" + std::to_string(p.ldsBytes) + " fill=" + std::to_string(p.fillRatio) + " ldsCycles=" +
-            std::to_string(p.ldsCycles) + "/" + std::to_string(p.ldsCyclesIdeal) + " reads=" + std::to_string(p.sweepReads) +
-            " entries=" + std::to_string(p.nEntries) + " back=" + std::to_string(p.backEdgesOnWalk);
+      msg = "tier A: " + p.key + " lds=" + std::to_string(p.ldsBytes) + " fill=" + std::to_string(p.fillRatio) +
+            " reads=" + std::to_string(p.sweepReads) + " entries=" + std::to_string(p.nEntries) + " back=" +
+            std::to_string(p.backEdgesOnWalk) + " sameWave=" + std::to_string(p.sameWave);
     }
     if (note && note_cap) { strncpy(note, msg.c_str(), note_cap - 1); note[note_cap - 1] = 0; }
     return DNAS_OK;

@@ -3,66 +3,44 @@
 // (reference src/viterbi.cpp:62-176) for machines whose state set fits one CU.
 //
 // One work-group (DNAS_T threads, one per CU) per read.  Thread t owns the states in
-// slots t, t+T, t+2T, ... ("rows" k = 0..K-1); their S and D cells of the current column
-// live in REGISTERS for the whole in-column fixpoint.  What other threads need is
-// published in LDS:
-//     X[slot]  = max(D+delExtend, S+delOpen)    every state  (what an emit edge reads, viterbi.cpp:124)
-//     DN[cell], SN[cell]                         states that are sources of null edges, or
-//                                                "heavy" destinations (in-degree > threshold)
-// The edge lists are compiled by the host into per-thread 32-bit entries that are loaded
-// into registers once per read; the row shape (entries per row) is a compile-time constant,
-// so every register index is static.  A column is: gather S of the previous column from
-// LDS -> sweep all rows until no cell grows (monotone max-plus: the least fixpoint is
-// schedule independent, so the cells equal the reference's worklist result bit for bit)
-// -> duplication lanes -> coalesced stores of the six lanes in slot order.
+// (row k, lane t), k = 0..K-1; their S and D cells of the current column live in REGISTERS
+// for the whole in-column fixpoint.  Like the reference's worklist (viterbi.cpp:110-159) the
+// recursion is PUSHED along the out-edges: every state owns an LDS accumulator
+//     DC[k*T + t]   what its in-edges have offered to its D cell       (all states)
+//     SC[stripe]    what its null in-edges have offered to its S cell  (rows with such states)
+// and a state whose cells grew offers  max(D+delExtend, S+delOpen)+score  to the DC of its emit
+// successors,  D+score / S+score  to DC / SC of its null successors (ds_max_f64).  A sweep
+// is: every thread walks its rows in order, reads the row's own accumulators (conflict-free:
+// consecutive lanes, consecutive cells), and pushes only where a cell grew.  The out-edge
+// lists are compiled by the host into per-thread 32-bit entries that are loaded into registers
+// once per read; the row shape (entries per row, S stripe) is a compile-time constant, so
+// every register index is static.  A column is: push S of the previous column along the emit
+// edges (viterbi.cpp:92-95) -> read it back as this column's S -> sweep until no cell grows
+// (monotone max-plus: the least fixpoint is schedule independent, so the cells equal the
+// reference's worklist result bit for bit) -> duplication lanes -> coalesced stores.
 //
 // fp64 throughout, reference operand order, no contraction / fast-math.
 //
 // Compile-time parameters (-D):  DNAS_T threads, DNAS_K rows, DNAS_D dup lanes,
-//   DNAS_NS slots (= K*T), DNAS_C LDS cells (incl. two dummies),
-//   DNAS_ROWS  brace list of {emit pulls, null pulls, pushes, publishes} per row.
+//   DNAS_NS slots (= K*T), DNAS_SROWS S stripes, DNAS_NCLS distinct edge scores,
+//   DNAS_ROWS  brace list of {out-edge entries, S stripe or -1} per row.
 #ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>   // hiprtc provides the device runtime implicitly
 #endif
 
 #ifndef DNAS_T
-#error "compile with -DDNAS_T= -DDNAS_K= -DDNAS_D= -DDNAS_NS= -DDNAS_C= -DDNAS_ROWS="
+#error "compile with -DDNAS_T= -DDNAS_K= -DDNAS_D= -DDNAS_NS= -DDNAS_SROWS= -DDNAS_NCLS= -DDNAS_ROWS="
 #endif
 
-// per row: emit pulls / null pulls by score class (class 0 adds 0.0, i.e. nothing), pushes, publishes
-struct RowShape { int e[4], n[4], ep, ec; };
+struct RowShape { int nOut, sIdx; };
 constexpr RowShape kRows[DNAS_K] = {DNAS_ROWS};
 
-constexpr int rowEE(int k) { return kRows[k].e[0] + kRows[k].e[1] + kRows[k].e[2] + kRows[k].e[3]; }
-constexpr int rowEN(int k) { return kRows[k].n[0] + kRows[k].n[1] + kRows[k].n[2] + kRows[k].n[3]; }
 constexpr int rowOffset(int k) {
   int o = 0;
-  for (int i = 0; i < k; ++i) o += rowEE(i) + rowEN(i) + kRows[i].ep + kRows[i].ec;
+  for (int i = 0; i < k; ++i) o += kRows[i].nOut;
   return o;
-}
-// score class of the e-th emit (null) pull of row k
-constexpr int emitClass(int k, int e) {
-  int c = 0;
-  while (e >= kRows[k].e[c]) { e -= kRows[k].e[c]; ++c; }
-  return c;
-}
-constexpr int nullClass(int k, int e) {
-  int c = 0;
-  while (e >= kRows[k].n[c]) { e -= kRows[k].n[c]; ++c; }
-  return c;
 }
 constexpr int kEntries = rowOffset(DNAS_K) > 0 ? rowOffset(DNAS_K) : 1;
-constexpr int emitSlotBase(int k) {
-  int o = 0;
-  for (int i = 0; i < k; ++i) o += rowEE(i);
-  return o;
-}
-constexpr int maxRowVals() {
-  int m = 0;
-  for (int k = 0; k < DNAS_K; ++k) m = rowEE(k) + 2 * rowEN(k) > m ? rowEE(k) + 2 * rowEN(k) : m;
-  return m;
-}
-constexpr int kMaxRowVals = maxRowVals();
 
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 static_assert(DNAS_K % 2 == 0, "rows come in pairs");
@@ -86,24 +64,23 @@ struct TierAArgs {
   double score[4];  // score table, score[0] == 0
 };
 
-// LDS map (bytes):  X[NS] | DN[C] | SN[C] | negInf | score[4] | sub[16] | len[8] | red[T/64] | epoch, idle[T/64] (u32)
-constexpr int kXBytes = DNAS_NS * 8;
-constexpr int kCellBytes = DNAS_C * 8;           // SN[cell] sits kCellBytes behind DN[cell]
-constexpr int kTabBase = kXBytes + 2 * kCellBytes + 8;
+// LDS map (bytes):  SC[SROWS*T] | pad | DC[NS] | score[4] | sub[16] | len[8] | red[T/64] | epoch, idle[T/64] (u32)
+constexpr int kDCBase = DNAS_SROWS * DNAS_T * 8 + 64;
+constexpr int kTabBase = kDCBase + DNAS_NS * 8;
 
-// entries (host/plan.cpp packs them).  Pull entries are bare LDS byte addresses -- X[src slot]
-// for an emit pull, DN[src cell] for a null pull -- and their score class is a compile-time
-// property of the entry's position in the row.  Push / publish entries carry flags:
-//   [0:19)  byte address of DN[cell]
-//   [19:24) score index << 3   (byte offset into the LDS score table)
-//   [24:26) emitted base       (emit push)
-//   [26]    flag: push = emit edge;  publish = heavy cell (also receives pushes)
-//   [27]    publish: state has a cell
-#define ENT_ADDR(e) ((e) & 0x7ffffu)
-#define ENT_SCOFF(e) (((e) >> 19) & 0x18u)
-#define ENT_BASE(e) (((e) >> 24) & 3u)
-#define ENT_FLAG(e) (((e) >> 26) & 1u)
-#define ENT_HASCELL(e) (((e) >> 27) & 1u)
+// entries (host/plan.cpp packs them), one per out-edge; every field is one or two VALU
+// operations away from its use:
+//   [0:2)   score class
+//   [3:18)  byte address of the destination's DC cell, >> 3       ->  en & 0x3fff8
+//   [19:32) null edge: index of the destination's SC cell          ->  (en >> 16) & 0xfff8 is its byte address
+//           emit edge: 0x1ffc | emitted base                       ->  en >= 0xffe00000
+//   0: no edge
+#define ENT_VALID(e) ((e) != 0u)
+#define ENT_EMIT(e) ((e) >= 0xffe00000u)
+#define ENT_DC(e) ((e) & 0x3fff8u)
+#define ENT_SC(e) (((e) >> 16) & 0xfff8u)
+#define ENT_CLS(e) ((e) & 3u)
+#define ENT_BASE32(e) (((e) >> 14) & 0x60u)   // emitted base * 32: byte offset of its row in the sub table
 
 // v_max_f64 directly: no NaN can occur here (only -inf + finite / -inf + -inf), so the
 // canonicalising copies the compiler would add around fmax() are pure overhead
@@ -121,23 +98,24 @@ __device__ __forceinline__ void ldsWrite(char* base, unsigned byteOff, double v)
 __device__ __forceinline__ void ldsMax(char* base, unsigned byteOff, double v) {
   __hip_atomic_fetch_max(reinterpret_cast<double*>(base + byteOff), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-// keep a register-resident entry opaque inside the sweep loop, so that nothing derived
-// from it is hoisted out and kept live across iterations
+
+// keep a register-resident entry opaque inside the column loop, so that nothing decoded from
+// it is hoisted out and kept live across iterations
 __device__ __forceinline__ unsigned opaque(unsigned v) {
   asm volatile("" : "+v"(v));
   return v;
 }
 
 constexpr double kNegInf = -__builtin_huge_val();
+constexpr double kFresh = __builtin_huge_val();   // "not evaluated in this column yet" in a D register
 
-#ifndef DNAS_PIPE
-#define DNAS_PIPE 1
+#ifndef DNAS_LOCKSTEP
+#define DNAS_LOCKSTEP 0
 #endif
 
 extern "C" __global__ void __launch_bounds__(DNAS_T)
 viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntries][T]
                    const unsigned* __restrict__ metaTab,                // [K][T]: mdl | ctx<<4 | flags
-                   const unsigned* __restrict__ baseTab,                // [DNAS_BASEWORDS][T]: base of each emit pull, 2 bits each
                    const unsigned char* __restrict__ bases, const unsigned long long* __restrict__ readOff,
                    const int* __restrict__ batchRead, const unsigned long long* __restrict__ slotOff,
                    double* __restrict__ arena, double* __restrict__ outLoglike,
@@ -147,9 +125,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
   constexpr int T = DNAS_T, K = DNAS_K, D_ = DNAS_D, lanes = 2, NS = DNAS_NS;   // stored lanes: S, D
   const int tid = threadIdx.x;
   char* const ldsB = reinterpret_cast<char*>(lds);
-  double* const X = lds;
   const double* const subL = lds + (kTabBase / 8) + 4;
-  const double* const lenL = subL + 16;
   // the vote words live in the same dynamic LDS block; a second extern array (same base) keeps
   // the accesses in the LDS address space (a volatile generic pointer would turn them into
   // flat_* operations that wait on every outstanding global store)
@@ -164,9 +140,16 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
   unsigned E[kEntries];
   static_for<0, kEntries>([&](auto m) { E[m.value] = entTab[(size_t)m.value * T + tid]; });
 #define META(k) (metaTab[(size_t)(k) * T + tid])
-  unsigned baseW[DNAS_BASEWORDS];   // emitted base of every emit pull of this thread, 2 bits each (phase A)
-  static_for<0, DNAS_BASEWORDS>([&](auto w) { baseW[w.value] = baseTab[(size_t)w.value * T + tid]; });
-  const double scoreC[4] = {0.0, a.score[1], a.score[2], a.score[3]};
+  // score of an edge by class: class 0 is 0.0 (adding it is the identity on every value that occurs)
+  auto withScore = [&](double v, unsigned cls) -> double {
+    if constexpr (DNAS_NCLS <= 1) return v;
+    else if constexpr (DNAS_NCLS == 2) return cls ? v + a.score[1] : v;
+    else return v + ldsRead(ldsB, kTabBase + cls * 8);
+  };
+  // own accumulators: byte addresses
+  const unsigned ownB = (unsigned)tid * 8u;
+#define DC_OWN(k) (ownB + (unsigned)kDCBase + (unsigned)(k) * T * 8u)
+#define SC_OWN(k) (ownB + (unsigned)kRows[k].sIdx * T * 8u)
 
   double S[K], Dv[K];   // after phase C, Dv[k] carries the T1 hand-over to the next column's phase A
   unsigned rounds = 0;
@@ -177,8 +160,8 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
 #define STAMP(acc)
 #endif
 
-  // LDS init: everything -inf (dummy cells / slots stay that way), then the small tables
-  for (int i = tid; i < NS + 2 * DNAS_C + 1; i += T) lds[i] = kNegInf;
+  // LDS init: every accumulator -inf, then the small tables
+  for (int i = tid; i < kTabBase / 8; i += T) lds[i] = kNegInf;
   if (tid < 4) lds[kTabBase / 8 + tid] = a.score[tid];
   if (tid < 16) lds[kTabBase / 8 + 4 + tid] = a.sub[tid];
   if (tid < 8) lds[kTabBase / 8 + 20 + tid] = a.len[tid];
@@ -211,76 +194,41 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
     t0 = __builtin_amdgcn_s_memtime();
 #endif
 
-    // ---- phase A (viterbi.cpp:75-79,92-95,101-103): S of this column from the previous
-    // column's S (parked in X[] by phase C) and the T1 lane (handed over in the D registers by phase C).
-    // Heavy destinations receive their emit-in candidates by ds_max pushes into SN[cell]
-    // (their owners reset the cell in phase C).
+    // ---- phase A (viterbi.cpp:75-79,92-95,101-103): S of this column.  Every state offers
+    // ((S(pos-1) + score) + noGap) + sub[base][x] along its emit edges into the destinations'
+    // DC (all -inf since phase C); after the barrier each state takes what it was offered,
+    // folds in the T1 lane (handed over in the D registers by phase C) and clears the cell for
+    // the D offers of the fixpoint.
     if (pos > 0) {
+      const unsigned subRow = (unsigned)kTabBase + 32u + (unsigned)x * 8u;   // &sub[0][x]
       static_for<0, K>([&](auto kc) {
         constexpr int k = kc.value, o = rowOffset(k);
-        static_for<0, kRows[k].ep>([&](auto ec) {
-          const unsigned en = E[o + rowEE(k) + rowEN(k) + ec.value];
-          if (ENT_FLAG(en)) {
-            const double cand = ((S[k] + ldsRead(ldsB, kTabBase + ENT_SCOFF(en))) + a.noGap) + subL[ENT_BASE(en) * 4 + x];
-            if (cand > kNegInf) ldsMax(ldsB, ENT_ADDR(en) + kCellBytes, cand);
-          }
-        });
+        if (S[k] > kNegInf) {
+          static_for<0, kRows[k].nOut>([&](auto ec) {
+            const unsigned en = opaque(E[o + ec.value]);
+            if (ENT_EMIT(en))
+              ldsMax(ldsB, ENT_DC(en), (withScore(S[k], ENT_CLS(en)) + a.noGap) + ldsRead(ldsB, subRow + ENT_BASE32(en)));
+          });
+        }
       });
+      __syncthreads();   // every offer of the previous column has landed
+      STAMP(tA)
       static_for<0, K>([&](auto kc) {
-        constexpr int k = kc.value, o = rowOffset(k);
-        double s = Dv[k];   // T1(pos-1) + sub[ctx1][x_pos], left there by phase C
-        static_for<0, rowEE(k)>([&](auto ec) {
-          constexpr int cls = emitClass(k, ec.value);
-          // (S(src) + score) + noGap + sub: "+ 0.0" of class 0 is the identity on every value that occurs
-          double v = ldsRead(ldsB, E[o + ec.value]);
-          if constexpr (cls != 0) v = v + scoreC[cls];
-          constexpr int slot = emitSlotBase(k) + ec.value;   // this thread's slot-th emit pull overall
-          s = dmax(s, (v + a.noGap) + subL[((baseW[slot / 16] >> (2 * (slot % 16))) & 3u) * 4 + x]);
-        });
-        S[k] = s;
+        constexpr int k = kc.value;
+        S[k] = dmax(ldsRead(ldsB, DC_OWN(k)), Dv[k]);   // Dv: T1(pos-1) + sub[ctx1][x_pos], left there by phase C
+        ldsWrite(ldsB, DC_OWN(k), kNegInf);
+        Dv[k] = kFresh;
       });
     } else {
       static_for<0, K>([&](auto kc) {
         constexpr int k = kc.value;
         const unsigned mt = META(k);    // bit29: real state, bit31: reference state 0
         S[k] = ((mt & 0x20000000u) && (a.local || (mt & 0x80000000u))) ? 0.0 : kNegInf;   // viterbi.cpp:75-79
+        Dv[k] = kFresh;
       });
+      STAMP(tA)
     }
-    __syncthreads();   // every gather of the previous column (and every phase-A push) is done
-    STAMP(tA)
-
-    // ---- start of the fixpoint: D = -inf, X = max(D+delExtend, S+delOpen); cells published;
-    // every push edge fired once with the starting values
-    static_for<0, K>([&](auto kc) {
-      constexpr int k = kc.value, o = rowOffset(k);
-      double s = S[k];
-      static_for<0, kRows[k].ec>([&](auto ec) {
-        const unsigned en = E[o + rowEE(k) + rowEN(k) + kRows[k].ep + ec.value];
-        if (ENT_HASCELL(en)) {
-          if (ENT_FLAG(en)) {        // heavy destination: fold in what phase A pushed, never lower the cell
-            s = dmax(s, ldsRead(ldsB, ENT_ADDR(en) + kCellBytes));
-            ldsMax(ldsB, ENT_ADDR(en) + kCellBytes, s);
-          } else {
-            ldsWrite(ldsB, ENT_ADDR(en) + kCellBytes, s);
-            ldsWrite(ldsB, ENT_ADDR(en), kNegInf);
-          }
-        }
-      });
-      S[k] = s;
-      Dv[k] = kNegInf;
-      const double xv = dmax(kNegInf + a.delExtend, s + a.delOpen);
-      X[k * T + tid] = xv;
-      static_for<0, kRows[k].ep>([&](auto ec) {
-        const unsigned en = E[o + rowEE(k) + rowEN(k) + ec.value];
-        const double sc = ldsRead(ldsB, kTabBase + ENT_SCOFF(en));
-        if (ENT_FLAG(en)) {
-          if (xv + sc > kNegInf) ldsMax(ldsB, ENT_ADDR(en), xv + sc);
-        } else {
-          if (s + sc > kNegInf) ldsMax(ldsB, ENT_ADDR(en) + kCellBytes, s + sc);
-        }
-      });
-    });
-    __syncthreads();
+    __syncthreads();   // every DC is cleared before the first offer of the fixpoint
     STAMP(tP)
 
     // ---- phase B: sweeps to the fixpoint (viterbi.cpp:97-99,110-159), WITHOUT a barrier per
@@ -291,82 +239,56 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
     //     idle[w]  = e+1 once wave w has finished a sweep that grew nothing and saw epoch == e
     //              from its first read to its last
     // When all waves are idle at the same epoch, nothing was written while each of them swept:
-    // every cell is consistent with its inputs, i.e. the fixpoint.  The LDS reads of row k+1 are
-    // issued before row k is evaluated (software pipeline).
+    // every cell is consistent with its inputs, i.e. the fixpoint.  A row's accumulators are
+    // read when its turn comes, so a value crosses every forward edge (source row < destination
+    // row) within one sweep -- the plan lays the machine's chains out along ascending rows.
     {
       constexpr int NW = DNAS_T / 64;
-      // DNAS_PIPE 1: the gathers of a row are issued when its turn comes, so a value crosses every
-      // forward edge (source row < destination row) within one sweep -- the plan lays chains out
-      // along ascending rows.  2: one row of read-ahead (a hop then needs two rows of distance).
-      constexpr int PIPE = DNAS_PIPE;
       const int wv = tid >> 6, ln = tid & 63;
       for (;;) {
         asm volatile("" ::: "memory");   // other waves write LDS between sweeps: reload everything
         const unsigned e0 = __hip_atomic_load(epochL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (ln == 0) __hip_atomic_store(&idleL[wv], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         int changed = 0;
-        double buf[PIPE][kMaxRowVals > 0 ? kMaxRowVals : 1];
-        auto issue = [&](auto kc) {
-          constexpr int k = kc.value, o = rowOffset(k), b = k % PIPE;
-#ifdef DNAS_DIAG_NO_LDS_READS   // timing experiment: what do the sweeps cost without their gathers
-          static_for<0, rowEE(k) + 2 * rowEN(k)>([&](auto ec) { buf[b][ec.value] = __uint_as_float(E[o]) > 3.f ? 1.0 : kNegInf; });
-#else
-          static_for<0, rowEE(k)>([&](auto ec) { buf[b][ec.value] = ldsRead(ldsB, E[o + ec.value]); });
-          static_for<0, rowEN(k)>([&](auto ec) {
-            const unsigned addr = E[o + rowEE(k) + ec.value];
-            buf[b][rowEE(k) + 2 * ec.value] = ldsRead(ldsB, addr);
-            buf[b][rowEE(k) + 2 * ec.value + 1] = ldsRead(ldsB, addr + kCellBytes);
-          });
-#endif
-        };
-        if constexpr (PIPE == 2) issue(IntC<0>{});
         static_for<0, K>([&](auto kc) {
-          constexpr int k = kc.value, o = rowOffset(k), b = k % PIPE;
-          if constexpr (PIPE == 1) issue(kc);
-          else if constexpr (k + 1 < K) issue(IntC<k + 1>{});
-          double s = S[k], d = Dv[k];
-          static_for<0, rowEE(k)>([&](auto ec) {
-            constexpr int cls = emitClass(k, ec.value);
-            double v = buf[b][ec.value];
-            if constexpr (cls != 0) v = v + scoreC[cls];
-            d = dmax(d, v);
-          });
-          static_for<0, rowEN(k)>([&](auto ec) {
-            constexpr int cls = nullClass(k, ec.value);
-            double vd = buf[b][rowEE(k) + 2 * ec.value], vs = buf[b][rowEE(k) + 2 * ec.value + 1];
-            if constexpr (cls != 0) { vd = vd + scoreC[cls]; vs = vs + scoreC[cls]; }
-            d = dmax(d, vd);
-            s = dmax(s, vs);
-          });
-          s = dmax(s, d + a.delEnd);
-          if (s != S[k] || d != Dv[k]) {
+          constexpr int k = kc.value, o = rowOffset(k);
+          // D is exactly what the in-edges have offered; a row with no S cells can only move when D
+          // moved.  The first sweep of a column finds Dv == kFresh (no D cell is ever +inf) and offers
+          // the starting values.
+          const double d = ldsRead(ldsB, DC_OWN(k));
+          double s = S[k];
+          bool grew = d != Dv[k];
+          if constexpr (kRows[k].sIdx >= 0) {
+            s = dmax(s, ldsRead(ldsB, SC_OWN(k)));
+            grew = grew || s != S[k];
+          }
+          if (grew) {
             changed = 1;
+            s = dmax(s, d + a.delEnd);                                 // viterbi.cpp:114-115
             S[k] = s;
             Dv[k] = d;
-            const double xv = dmax(d + a.delExtend, s + a.delOpen);
-            X[k * T + tid] = xv;
-            static_for<0, kRows[k].ec>([&](auto ec) {
-              const unsigned en = E[o + rowEE(k) + rowEN(k) + kRows[k].ep + ec.value];
-              if (ENT_HASCELL(en)) {   // a heavy destination's cell also receives pushes: only ever raise it
-                ldsMax(ldsB, ENT_ADDR(en) + kCellBytes, s);
-                ldsMax(ldsB, ENT_ADDR(en), d);
-              }
-            });
-            static_for<0, kRows[k].ep>([&](auto ec) {
-              const unsigned en = E[o + rowEE(k) + rowEN(k) + ec.value];
-              const double sc = ldsRead(ldsB, kTabBase + ENT_SCOFF(en));
-              if (ENT_FLAG(en)) {
-                ldsMax(ldsB, ENT_ADDR(en), xv + sc);
-              } else {
-                ldsMax(ldsB, ENT_ADDR(en), d + sc);
-                ldsMax(ldsB, ENT_ADDR(en) + kCellBytes, s + sc);
+            const double xv = dmax(d + a.delExtend, s + a.delOpen);    // viterbi.cpp:124
+            static_for<0, kRows[k].nOut>([&](auto ec) {
+              const unsigned en = opaque(E[o + ec.value]);
+              if (ENT_VALID(en)) {
+                if (ENT_EMIT(en)) {
+                  ldsMax(ldsB, ENT_DC(en), withScore(xv, ENT_CLS(en)));
+                } else {                                               // viterbi.cpp:137-151
+                  ldsMax(ldsB, ENT_DC(en), withScore(d, ENT_CLS(en)));
+                  ldsMax(ldsB, ENT_SC(en), withScore(s, ENT_CLS(en)));
+                }
               }
             });
           }
         });
+#if DNAS_LOCKSTEP   // experiment: a barrier per sweep keeps the waves in step
+        ++rounds;
+        if (!__syncthreads_or(changed)) break;
+      }
+#else
         ++rounds;
         if (__any(changed)) {
-          // the data writes above precede the bump (LDS operations of one wave execute in order)
+          // the offers above precede the bump (LDS operations of one wave execute in order)
           if (ln == 0) __hip_atomic_fetch_add(epochL, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
           continue;
         }
@@ -381,12 +303,13 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
         }
         if (done) break;
       }
-      __syncthreads();   // all waves are out of the sweeps before phase C reuses X[]
+#endif
+      __syncthreads();   // all waves are out of the sweeps before phase C clears the accumulators
     }
     STAMP(tB)
 
-    // ---- phase C: the column's S and D lanes go to HBM in slot order (coalesced); S is parked
-    // in X[] for the next column's gathers; heavy cells are reset.  The duplication lanes
+    // ---- phase C: the column's S and D lanes go to HBM in slot order (coalesced); the
+    // accumulators are cleared for the next column's offers.  The duplication lanes
     // T1..TD (viterbi.cpp:105-106,161-168) are NOT stored: T(pos,q) is a function of this
     // state's own S(pos), S(pos-1), ... S(pos-(D-1)) and the read,
     //     T(p,q) = max( T(p-1,q+1) + sub[ctx[q+1]][x_p],  (S(p)+tanDup)+len[q] ),   T(0,.) = -inf,
@@ -428,17 +351,11 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
           }
         });
         static_for<k0, k1>([&](auto kc) {
-          constexpr int k = kc.value, o = rowOffset(k);
+          constexpr int k = kc.value;
           const double s = S[k];
           const int mdl = (int)(metaG[k - k0] & 15u);
-          X[k * T + tid] = s;
-          static_for<0, kRows[k].ec>([&](auto ec) {
-            const unsigned en = E[o + rowEE(k) + rowEN(k) + kRows[k].ep + ec.value];
-            if (ENT_HASCELL(en) && ENT_FLAG(en)) {
-              ldsWrite(ldsB, ENT_ADDR(en) + kCellBytes, kNegInf);
-              ldsWrite(ldsB, ENT_ADDR(en), kNegInf);
-            }
-          });
+          ldsWrite(ldsB, DC_OWN(k), kNegInf);
+          if constexpr (kRows[k].sIdx >= 0) ldsWrite(ldsB, SC_OWN(k), kNegInf);
           // T1(pos): chain from the deepest element (i = D-1) to i = 0.  Nearly every state has a
           // full context (mdl == D) and nearly every column a full history: that case is straight
           // line code, chosen per wave.
@@ -479,7 +396,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
       // between two groups would sit in front of the next group's history loads
       STORE_LANE(pos, 0, S)
     }
-    __syncthreads();   // X[] now holds S(pos) for everyone
+    __syncthreads();   // every accumulator is -inf again
     STAMP(tC)
   }
 #ifdef DNAS_STAMP

@@ -100,6 +100,7 @@ def lib():
         "dnas_model_sync": (ctypes.c_int, [vp]),
         "dnas_model_tier": (cp, [vp]),
         "dnas_tiera_plan_slots": (ctypes.c_int, [P(FlatModelC), vp, vp, vp, vp]),
+        "dnas_tiera_plan_tables": (ctypes.c_int, [P(FlatModelC), vp, vp, ctypes.c_size_t, vp, vp, vp]),
         "dnas_model_debug_words": (ctypes.c_int, [vp, vp]),
         "dnas_tiera_precompile": (ctypes.c_int, [P(FlatModelC), ctypes.c_char_p, sz]),
         "dnas_model_last_stats": (ctypes.c_int, [vp, P(BatchStatsC)]),

@@ -161,6 +161,12 @@ int dnas_tiera_precompile(const dnas_flat_model *fm, char *note, size_t note_cap
 int dnas_tiera_plan_slots(const dnas_flat_model *fm, int32_t *lds_index, int32_t *lattice_slot, int32_t *threads,
                           int32_t *rows);
 
+/* Analysis / test aid: the tier-A tables exactly as the fill kernel receives them (layout:
+ * dnastore_amd/csrc/viterbi_tiera.hip).  row_shapes[rows][2] = {out-edge entries, S stripe or -1};
+ * entries[n_entries][threads]; meta[rows][threads].  Any output may be NULL. */
+int dnas_tiera_plan_tables(const dnas_flat_model *fm, int32_t *row_shapes, uint32_t *entries, size_t entries_cap,
+                           uint32_t *meta, int32_t *n_entries, int32_t *n_s_rows);
+
 /* Diagnostic: 8 words of the kernel's rounds/stamp buffer (word 0 = total rounds; words 1-5 are filled only by
  * a -DDNAS_STAMP diagnostic build selected with DNAS_TIERA_DEFS). */
 int dnas_model_debug_words(dnas_model *model, unsigned long long *out8);

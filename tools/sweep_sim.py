@@ -53,12 +53,18 @@ class Sim:
             x, y = a["ein_ptr"][j], a["ein_ptr"][j + 1]
             self.eB[j, :y - x] = a["ein_base"][x:y]
 
-    def run(self, seq, row_of, K, pipe=2, max_cols=None, verbose=False):
+    def run(self, seq, row_of, K, pipe=2, max_cols=None, verbose=False, lane_of=None):
+        """lane_of given: edges between different waves (lane // 64) only deliver what the source held at
+        the start of the sweep (pessimistic model of waves that drift apart)."""
         N, D = self.N, self.D
         a = self.a
         mdl = a["mdl"].astype(np.int64)
         ctx = a["ctx"].astype(np.int64)
         rows = [np.nonzero(row_of == k)[0] for k in range(K)]
+        if lane_of is not None:
+            wave = lane_of // 64
+            eSame = wave[self.eS] == wave[:, None]
+            nSame = wave[self.nS] == wave[:, None]
         S = np.full(N, NEG); S[0] = 0.0
         T = np.full((N, max(D, 1)), NEG)
         L = len(seq)
@@ -86,14 +92,20 @@ class Sim:
             while True:
                 n_sw += 1
                 changed = False
+                X0, D0, S0 = X.copy(), Dl.copy(), S.copy()
                 pending = []   # (k, gathered values) queue to model the read-ahead
                 hist = []
                 for k in range(K + pipe - 1):
                     if k < K and len(rows[k]):
                         r = rows[k]
-                        ge = (X[self.eS[r]] + self.eW[r]).max(axis=1)
-                        gd = (Dl[self.nS[r]] + self.nW[r]).max(axis=1)
-                        gs = (S[self.nS[r]] + self.nW[r]).max(axis=1)
+                        if lane_of is None:
+                            ge = (X[self.eS[r]] + self.eW[r]).max(axis=1)
+                            gd = (Dl[self.nS[r]] + self.nW[r]).max(axis=1)
+                            gs = (S[self.nS[r]] + self.nW[r]).max(axis=1)
+                        else:
+                            ge = (np.where(eSame[r], X[self.eS[r]], X0[self.eS[r]]) + self.eW[r]).max(axis=1)
+                            gd = (np.where(nSame[r], Dl[self.nS[r]], D0[self.nS[r]]) + self.nW[r]).max(axis=1)
+                            gs = (np.where(nSame[r], S[self.nS[r]], S0[self.nS[r]]) + self.nW[r]).max(axis=1)
                         pending.append((k, ge, gd, gs))
                     elif k < K:
                         pending.append((k, None, None, None))
