@@ -4,7 +4,7 @@
 #include <stdint.h>
 
 constexpr int kFillThreads = 512;   // work-group size of viterbi_fill_kernel (8 waves)
-constexpr int kTraceThreads = 64;   // one wave of independent reads per traceback block
+constexpr int kTraceThreads = 512;  // independent reads per traceback block: a whole batch sits on ONE CU (see runtime.hip)
 constexpr int kMaxLen = 32;         // pLen entries (dnas_mutator_params.p_len)
 
 struct DevModel {

@@ -2,6 +2,8 @@
 
 #include <algorithm>
 #include <array>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <numeric>
@@ -71,9 +73,10 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
   // (states with null in-edges) -- and the states are dealt onto it along a depth-first walk
   // of the machine, each state into the first row behind its parent's row whose shape admits
   // it: a chain runs down the rows of one sweep instead of along one row.  Candidate programs
-  // (how many S rows, in how many groups, uniform or ascending entry counts) are scored by
-  // (LDS reads per sweep) x (sweeps, estimated as the largest number of backward edges on any
-  // walk of kWalk edges); the best one that fits the registers and the LDS is kept.
+  // (how many S rows, in how many groups, uniform or ascending entry counts, last row left empty)
+  // are scored by (cost of a sweep: accumulator reads + entries) x (sweeps, estimated as the
+  // largest number of backward edges on any walk of kWalk edges); the best one that fits the
+  // registers and the LDS is kept.
   std::vector<int> pre(N, -1), parent(N, -1), walk;
   walk.reserve(N);
   {
@@ -159,8 +162,10 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
     std::vector<Type> shape(K, Type{0, 0});
     for (int j = 0; j < N; ++j)
       for (int q = 0; q < 2; ++q) shape[rows[j]][q] = std::max(shape[rows[j]][q], type[j][q]);
+    std::vector<char> inUse(K, 0);
+    for (int j = 0; j < N; ++j) inUse[rows[j]] = 1;
     int reads = 0, entries = 0;
-    for (const Type& r : shape) { reads += 1 + r[1]; entries += r[0]; }
+    for (int k = 0; k < K; ++k) if (inUse[k]) { reads += 1 + shape[k][1]; entries += shape[k][0]; }
     std::vector<int> f(N, 0), g(N);
     for (int h = 0; h < kWalk; ++h) {
       std::fill(g.begin(), g.end(), 0);
@@ -173,7 +178,8 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
     int back = 0;
     for (int v : f) back = std::max(back, v);
     *readsOut = reads; *backOut = back; *entriesOut = entries;
-    return (double)(reads + 10) * (double)(back + 1);
+    // a sweep costs its accumulator reads plus, where cells grew, one offer per entry
+    return (double)(reads + entries + 10) * (double)(back + 1);
   };
   auto ldsNeed = [&](int nS) { return (size_t)(p.NS + nS * T + 8 + 28 + T / 64 + (T / 64 + 2) / 2 + 1) * sizeof(double); };
 
@@ -188,17 +194,20 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
     const int minS = (nNullDest + T - 1) / T;
     double bestScore = -1;
     std::string why = "no row program fits";
-    for (int nS = minS; nS <= std::min(K, minS + 2); ++nS) {
+    // K is even (lattice pairs); when the states fit K-1 rows the last one may stay empty and
+    // costs nothing in a sweep -- tried both ways
+    for (int KU = K; KU >= std::max(1, K - 1); --KU)
+    for (int nS = minS; nS <= std::min(KU, minS + 2); ++nS) {
       if (ldsNeed(nS) > kTierALdsLimit) { why = "LDS working set " + std::to_string(ldsNeed(nS)) + " B exceeds one CU"; continue; }
-      if ((size_t)(K - nS) * T + (size_t)nS * T < (size_t)N) continue;
+      if ((size_t)KU * T < (size_t)N) continue;
       for (int groups = 1; groups <= std::max(1, std::min(3, nS)); ++groups) {
         for (int ascending = 0; ascending < 2; ++ascending) {
           // kinds: the S rows in `groups` runs spread evenly over the program
           std::vector<int> isS(K, 0);
           for (int g = 0, left = nS; g < groups && nS > 0; ++g) {
             const int len = left / (groups - g);
-            const int at = g * K / groups;
-            for (int i = 0; i < len; ++i) isS[std::min(K - 1, at + i)] = 1;
+            const int at = g * KU / groups;
+            for (int i = 0; i < len; ++i) isS[std::min(KU - 1, at + i)] = 1;
             left -= len;
           }
           if (std::accumulate(isS.begin(), isS.end(), 0) != nS) continue;   // runs collided
@@ -212,13 +221,20 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
               const size_t q = std::min(sorted.size() - 1, (size_t)(seen + 1) * T - 1);
               cap = (size_t)(seen + 1) * T >= sorted.size() ? maxOut : sorted[q];
             }
-            caps[k] = Type{cap, isS[k]};
+            caps[k] = k < KU ? Type{cap, isS[k]} : Type{-1, -1};   // closed rows admit nothing
             ++seen;
           }
           std::vector<int> rows;
           if (!deal(caps, &rows)) continue;
           int reads = 0, back = 0, entries = 0;
           const double sc = score(rows, &reads, &back, &entries);
+          if (getenv("DNAS_PLAN_DEBUG"))
+            fprintf(stderr, "plan candidate: rows %d S-rows %d groups %d ascending %d -> reads %d entries %d back %d score %.0f\n", KU, nS,
+                    groups, ascending, reads, entries, back, sc);
+          if (const char* pick = getenv("DNAS_PLAN_PICK")) {   // experiments: "rows,S-rows,groups,ascending"
+            int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            if (sscanf(pick, "%d,%d,%d,%d", &a0, &a1, &a2, &a3) == 4 && (a0 != KU || a1 != nS || a2 != groups || a3 != ascending)) continue;
+          }
           if (entries > kMaxEntries) { why = "row shapes need " + std::to_string(entries) + " entry registers per thread"; continue; }
           if (bestScore < 0 || sc < bestScore) {
             bestScore = sc; rowOfState = rows; bestCaps = caps;
@@ -306,11 +322,12 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
   }
   p.nSRows = 0;
   for (int k = 0; k < K; ++k) if (needS[k]) p.rows[k].sIdx = p.nSRows++;
+  for (int k = 0; k < K; ++k) if (rowMembers[k].empty()) p.rows[k].nOut = -1;   // the kernel skips the row
   p.ldsBytes = ldsNeed(p.nSRows);
   if (p.ldsBytes > kTierALdsLimit) return no("LDS working set " + std::to_string(p.ldsBytes) + " B exceeds one CU");
   int nEnt = 0;
   std::vector<int> rowOff(K, 0);
-  for (int k = 0; k < K; ++k) { rowOff[k] = nEnt; nEnt += p.rows[k].nOut; }
+  for (int k = 0; k < K; ++k) { rowOff[k] = nEnt; nEnt += std::max(p.rows[k].nOut, 0); }
   p.nEntries = std::max(nEnt, 1);
   p.fillRatio = nEnt ? (double)real / ((double)nEnt * T) : 1.0;
 

@@ -206,6 +206,15 @@ extern "C" int dnas_model_create(const dnas_flat_model* fm, int device_id, size_
   size_t freeB = 0, totalB = 0;
   if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return bail(dnas::fail(DNAS_E_DEVICE, "hipMemGetInfo failed"));
   m->arenaCap = arena_bytes ? arena_bytes : (size_t)((double)freeB * 0.6);
+  if (m->tier == 1) {
+    // A tier-A work-group owns a whole CU (all of its vector registers and nearly all of its LDS),
+    // so a launch runs in rounds of one read per CU.  The traceback of the previous batch runs
+    // beside the fill on one CU (a single block): a launch of two rounds over the REMAINING CUs
+    // ends with them, while one work-group more would wait for a third round.
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 1)
+      m->maxSlots = std::max(1, 2 * (cus - 1));
+  }
   if (const char* s = getenv("DNAS_MAX_SLOTS")) m->maxSlots = std::max(1, atoi(s));
   *out = m;
   return DNAS_OK;
@@ -279,6 +288,9 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
   std::vector<int64_t> batchStart{0};
   size_t used = 0, peak = 0;
   int64_t columns = 0;
+  // equal batches rather than full ones and a remainder
+  const int64_t nFull = (n_reads + m->maxSlots - 1) / m->maxSlots;
+  const int64_t perBatch = (n_reads + nFull - 1) / nFull;
   for (int64_t i = 0; i < n_reads; ++i) {
     const uint64_t L = read_offsets[order[i] + 1] - read_offsets[order[i]];
     if (L > 0x7ffffff0ull) return dnas::fail(DNAS_E_UNSUPPORTED, "read too long");
@@ -286,7 +298,7 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
     if (need > arenaCapDoubles)
       return dnas::fail(DNAS_E_NOMEM, "a single read's lattice (" + std::to_string(need * 8) +
                                           " bytes) exceeds the lattice arena (" + std::to_string(m->arenaCap) + ")");
-    if (i - batchStart.back() >= m->maxSlots || used + need > arenaCapDoubles) {
+    if (i - batchStart.back() >= perBatch || used + need > arenaCapDoubles) {
       batchStart.push_back(i);
       used = 0;
     }

@@ -23,7 +23,7 @@
 //
 // Compile-time parameters (-D):  DNAS_T threads, DNAS_K rows, DNAS_D dup lanes,
 //   DNAS_NS slots (= K*T), DNAS_SROWS S stripes, DNAS_NCLS distinct edge scores,
-//   DNAS_ROWS  brace list of {out-edge entries, S stripe or -1} per row.
+//   DNAS_ROWS  brace list of {out-edge entries (-1: row left empty), S stripe or -1} per row.
 #ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>   // hiprtc provides the device runtime implicitly
 #endif
@@ -35,9 +35,11 @@
 struct RowShape { int nOut, sIdx; };
 constexpr RowShape kRows[DNAS_K] = {DNAS_ROWS};
 
+constexpr bool rowLive(int k) { return kRows[k].nOut >= 0; }      // nOut -1: the plan left the row empty
+constexpr int rowOut(int k) { return kRows[k].nOut > 0 ? kRows[k].nOut : 0; }
 constexpr int rowOffset(int k) {
   int o = 0;
-  for (int i = 0; i < k; ++i) o += kRows[i].nOut;
+  for (int i = 0; i < k; ++i) o += rowOut(i);
   return o;
 }
 constexpr int kEntries = rowOffset(DNAS_K) > 0 ? rowOffset(DNAS_K) : 1;
@@ -203,8 +205,8 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
       const unsigned subRow = (unsigned)kTabBase + 32u + (unsigned)x * 8u;   // &sub[0][x]
       static_for<0, K>([&](auto kc) {
         constexpr int k = kc.value, o = rowOffset(k);
-        if (S[k] > kNegInf) {
-          static_for<0, kRows[k].nOut>([&](auto ec) {
+        if (rowLive(k) && S[k] > kNegInf) {
+          static_for<0, rowOut(k)>([&](auto ec) {
             const unsigned en = opaque(E[o + ec.value]);
             if (ENT_EMIT(en))
               ldsMax(ldsB, ENT_DC(en), (withScore(S[k], ENT_CLS(en)) + a.noGap) + ldsRead(ldsB, subRow + ENT_BASE32(en)));
@@ -215,16 +217,18 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
       STAMP(tA)
       static_for<0, K>([&](auto kc) {
         constexpr int k = kc.value;
-        S[k] = dmax(ldsRead(ldsB, DC_OWN(k)), Dv[k]);   // Dv: T1(pos-1) + sub[ctx1][x_pos], left there by phase C
-        ldsWrite(ldsB, DC_OWN(k), kNegInf);
-        Dv[k] = kFresh;
+        if constexpr (rowLive(k)) {
+          S[k] = dmax(ldsRead(ldsB, DC_OWN(k)), Dv[k]);   // Dv: T1(pos-1) + sub[ctx1][x_pos], left there by phase C
+          ldsWrite(ldsB, DC_OWN(k), kNegInf);
+          Dv[k] = kFresh;
+        }
       });
     } else {
       static_for<0, K>([&](auto kc) {
         constexpr int k = kc.value;
         const unsigned mt = META(k);    // bit29: real state, bit31: reference state 0
         S[k] = ((mt & 0x20000000u) && (a.local || (mt & 0x80000000u))) ? 0.0 : kNegInf;   // viterbi.cpp:75-79
-        Dv[k] = kFresh;
+        Dv[k] = rowLive(k) ? kFresh : kNegInf;   // an empty row stays (-inf, -inf) for the whole read
       });
       STAMP(tA)
     }
@@ -252,6 +256,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
         int changed = 0;
         static_for<0, K>([&](auto kc) {
           constexpr int k = kc.value, o = rowOffset(k);
+          if constexpr (!rowLive(k)) return;
           // D is exactly what the in-edges have offered; a row with no S cells can only move when D
           // moved.  The first sweep of a column finds Dv == kFresh (no D cell is ever +inf) and offers
           // the starting values.
@@ -268,7 +273,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
             S[k] = s;
             Dv[k] = d;
             const double xv = dmax(d + a.delExtend, s + a.delOpen);    // viterbi.cpp:124
-            static_for<0, kRows[k].nOut>([&](auto ec) {
+            static_for<0, rowOut(k)>([&](auto ec) {
               const unsigned en = opaque(E[o + ec.value]);
               if (ENT_VALID(en)) {
                 if (ENT_EMIT(en)) {
@@ -333,13 +338,14 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
       static_for<0, (K + G - 1) / G>([&](auto gc) {
         constexpr int k0 = gc.value * G, k1 = (k0 + G < K) ? k0 + G : K;
         unsigned metaG[G];
-        static_for<k0, k1>([&](auto kc) { metaG[kc.value - k0] = META(kc.value); });
+        static_for<k0, k1>([&](auto kc) { metaG[kc.value - k0] = rowLive(kc.value) ? META(kc.value) : 0u; });
         double sh[G][D_ > 1 ? D_ - 1 : 1];
         static_for<1, D_>([&](auto ic) {
           constexpr int i = ic.value;
           if (pos - i >= 1) {
             static_for<k0 / 2, k1 / 2>([&](auto mc) {
               constexpr int m2 = mc.value;
+              if constexpr (!rowLive(2 * m2) && !rowLive(2 * m2 + 1)) return;
 #ifdef DNAS_DIAG_NO_HIST   // timing experiment
               dbl2 v2; v2.x = S[2 * m2]; v2.y = S[2 * m2 + 1];
 #else
@@ -352,6 +358,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
         });
         static_for<k0, k1>([&](auto kc) {
           constexpr int k = kc.value;
+          if constexpr (!rowLive(k)) { Dv[k] = kNegInf; return; }
           const double s = S[k];
           const int mdl = (int)(metaG[k - k0] & 15u);
           ldsWrite(ldsB, DC_OWN(k), kNegInf);
