@@ -338,7 +338,9 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
       static_for<0, (K + G - 1) / G>([&](auto gc) {
         constexpr int k0 = gc.value * G, k1 = (k0 + G < K) ? k0 + G : K;
         unsigned metaG[G];
-        static_for<k0, k1>([&](auto kc) { metaG[kc.value - k0] = rowLive(kc.value) ? META(kc.value) : 0u; });
+        static_for<k0, k1>([&](auto kc) {   // (address rebuilt here: 14 hoisted pointers would cost 28 registers)
+          metaG[kc.value - k0] = rowLive(kc.value) ? metaTab[(size_t)kc.value * T + opaque((unsigned)tid)] : 0u;
+        });
         double sh[G][D_ > 1 ? D_ - 1 : 1];
         static_for<1, D_>([&](auto ic) {
           constexpr int i = ic.value;
