@@ -72,3 +72,60 @@ def gather_results(sym, out_len, loglike, status, world, rank):
     if rank != 0:
         return None
     return [tuple(outs[f][r] for f in range(4)) for r in range(world)]
+
+
+def shard_pairs(pk, world, rank):
+    """Alignment pairs of a packed Stockholm set (api.StockholmDB.arrays() layout) for one rank: pairs
+    are dealt like reads (by output length, snake order).  Returns a dict of the same layout."""
+    n = int(pk["n"])
+    if world <= 1:
+        return pk
+    lengths = np.diff(np.asarray(pk["out_off"], dtype=np.int64))
+    mine = partition(lengths, world)[rank]
+
+    def take(data, off):
+        off = np.asarray(off, dtype=np.int64)
+        segs = [np.asarray(data)[off[i]:off[i + 1]] for i in mine]
+        new_off = np.zeros(len(mine) + 1, dtype=np.int64)
+        if len(mine):
+            new_off[1:] = np.cumsum([len(s) for s in segs])
+        flat = np.concatenate(segs) if segs else np.asarray(data)[:0]
+        return np.ascontiguousarray(flat), new_off
+
+    out = {"n": len(mine)}
+    for d, o in (("ins", "in_off"), ("outs", "out_off"), ("cm_in", "cm_in_off"), ("cm_out", "cm_out_off")):
+        out[d], out[o] = take(pk[d], pk[o])
+    assert n >= len(mine)
+    return out
+
+
+def allreduce_counts(counts, ll, world, device="cpu"):
+    """The reduction of the E-step (fwdback.cpp:204-205: counts += stockCounts; ll += ...): one
+    all-reduce(sum) of the 21+P expected counts and the log-likelihood over the ranks (RCCL over xGMI on
+    GPUs, gloo in the CPU tests).  The fp64 summation order differs from the serial loop, so parity with
+    the single-process result is to ~1e-12 relative, not bit for bit."""
+    if not _dist_ready(world):
+        return np.asarray(counts, dtype=np.float64), float(ll)
+    t = torch.empty(len(counts) + 1, dtype=torch.float64, device=device)
+    t[:-1] = torch.as_tensor(np.asarray(counts, dtype=np.float64), device=device)
+    t[-1] = float(ll)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    t = t.cpu().numpy()
+    return t[:-1].copy(), float(t[-1])
+
+
+def expected_counts_sharded(params, pk, world, rank, estep, device="cpu"):
+    """Expected counts of the whole set with the pairs sharded over the ranks.  estep(params, shard_dict)
+    -> (counts, ll, ...) is the per-rank E-step (api.expectedCounts on a GPU)."""
+    mine = shard_pairs(pk, world, rank)
+    if int(mine["n"]) > 0:
+        res = estep(params, mine)
+        counts, ll = res[0], res[1]
+    else:
+        counts, ll = None, 0.0
+    n_counts = torch.tensor([0 if counts is None else len(counts)], dtype=torch.int64, device=device)
+    if _dist_ready(world):
+        dist.all_reduce(n_counts, op=dist.ReduceOp.MAX)
+    if counts is None:
+        counts = np.zeros(int(n_counts.item()))
+    return allreduce_counts(counts, ll, world, device)

@@ -104,3 +104,57 @@ def test_scatter_decode_gather_matches_single_process(world):
             assert olen[j] == ref_len[i] and ll[j] == ref_ll[i] and st[j] == ref_st[i]
             assert np.array_equal(sym[j * cap:(j + 1) * cap], ref_sym[i * cap:(i + 1) * cap])
     assert seen == set(range(n))
+
+
+def _unpack(pk):
+    """packed pair arrays -> list of (ins, outs, cmIn, cmOut)"""
+    out = []
+    for i in range(int(pk["n"])):
+        out.append(tuple(np.asarray(pk[d])[int(pk[o][i]):int(pk[o][i + 1])]
+                         for d, o in (("ins", "in_off"), ("outs", "out_off"), ("cm_in", "cm_in_off"), ("cm_out", "cm_out_off"))))
+    return out
+
+
+def _pairs(O):
+    import random
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from synth import synthetic_alignment
+    rng = random.Random(11)
+    return [O.alignment_pair(synthetic_alignment(rng, rng.choice([3, 20, 64, 101]), sub=.03, dele=.02, dup=.02)) for _ in range(13)]
+
+
+def _estep_worker(rank, world, port, stk, q):
+    sys.path.insert(0, ROOT)
+    from dnastore_amd import shard
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pk = O.pack_pairs(_pairs(O))
+    params = O.MutatorParams.from_cli(length=6)
+    # the per-rank E-step: the CPU oracle stands in for the GPU kernel (no GPU in this test)
+    counts, ll = shard.expected_counts_sharded(params, pk, world, rank, lambda p, d: O.expected_counts(p, _unpack(d)))
+    if rank == 0:
+        q.put((counts, ll))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_estep_allreduce_matches_single_process():
+    """fwd-back: pairs sharded over 2 ranks + all-reduce(sum) of counts and log-likelihood == one process."""
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as O
+    stk = None
+    want = O.expected_counts(O.MutatorParams.from_cli(length=6), _pairs(O))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_estep_worker, args=(r, 2, port, stk, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    counts, ll = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    np.testing.assert_allclose(counts, want[0], rtol=1e-12, atol=1e-300)
+    assert abs(ll - want[1]) <= 1e-12 * max(1.0, abs(want[1]))

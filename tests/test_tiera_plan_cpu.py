@@ -1,0 +1,149 @@
+"""CPU check of the tier-A plan (dnastore_amd/csrc/host/plan.cpp): the tables the HIP fill kernel
+receives -- placement, row shapes, out-edge entries, S stripes -- are executed by a plain numpy
+restatement of the kernel's column recurrence (push along out-edges into per-state accumulators,
+sweep to the fixpoint) and every S and D cell is compared, bit for bit, with the oracle's lattice.
+No GPU: this pins the host side of tier A; the kernel itself is covered by the `-m gpu` tests."""
+import os
+
+import numpy as np
+import pytest
+
+NEG = -np.inf
+
+
+def _emulate(fm, seq, local):
+    """S and D lanes [L+1][N] computed from the plan tables alone (+ the score scalars of the flat model)."""
+    a = fm.arrays()
+    N, D = a["n_states"], a["max_dup_len"]
+    sc = a["scores"]
+    del_open, tan_dup, no_gap, del_extend, del_end = sc[:5]
+    sub = sc[5:21].reshape(4, 4)
+    length = sc[21:]
+    shapes, ent, meta, n_s = fm.plan_tables()
+    lds_idx, _, T, K = fm.plan_slots()
+    dc_base = n_s * T * 8 + 64
+    # distinct edge scores in the plan's class order: 0.0 first, then by first appearance over destinations
+    scores = [0.0]
+    for j in range(N):
+        for v in list(a["ein_score"][a["ein_ptr"][j]:a["ein_ptr"][j + 1]]) + list(a["nin_score"][a["nin_ptr"][j]:a["nin_ptr"][j + 1]]):
+            if v not in scores:
+                scores.append(v)
+    row_off = np.concatenate([[0], np.cumsum(np.maximum(shapes[:, 0], 0))])
+    state_at = np.full(K * T, -1, dtype=np.int64)
+    state_at[lds_idx] = np.arange(N)
+    # decode the entries into per-state out-edge lists
+    out = [[] for _ in range(N)]
+    for j in range(N):
+        k, t = divmod(int(lds_idx[j]), T)
+        assert shapes[k, 0] >= 0, "state placed in a row the plan marks empty"
+        for e in range(int(shapes[k, 0])):
+            en = int(ent[row_off[k] + e, t])
+            if en == 0:
+                continue
+            dst_idx = ((en & 0x3fff8) - dc_base) // 8
+            dst = int(state_at[dst_idx])
+            assert dst >= 0, "entry points at an empty slot"
+            cls = en & 3
+            if en >= 0xffe00000:
+                out[j].append((dst, cls, (en >> 19) & 3, None))
+            else:
+                sc_idx = en >> 19
+                drow = dst_idx // T
+                assert shapes[drow, 1] >= 0 and sc_idx == shapes[drow, 1] * T + dst_idx % T, "S cell of a null edge is not the destination's"
+                out[j].append((dst, cls, 0, sc_idx))
+    has_s = np.array([shapes[int(lds_idx[j]) // T, 1] >= 0 for j in range(N)])
+    mdl = a["mdl"].astype(int)
+    ctx = a["ctx"].astype(int)
+    L = len(seq)
+    S_lat = np.full((L + 1, N), NEG)
+    D_lat = np.full((L + 1, N), NEG)
+    S = np.full(N, NEG)
+    Tl = np.full((N, max(D, 1)), NEG)
+    for pos in range(L + 1):
+        DC = np.full(N, NEG)
+        SC = np.full(N, NEG)
+        if pos == 0:
+            S[:] = 0.0 if local else NEG
+            S[0] = 0.0
+        else:
+            x = int(seq[pos - 1])
+            for j in range(N):                                   # phase A: offers along the emit edges
+                if S[j] > NEG:
+                    for dst, cls, base, sc_idx in out[j]:
+                        if sc_idx is None:
+                            DC[dst] = max(DC[dst], ((S[j] + scores[cls]) + no_gap) + sub[base][x])
+            Sn = DC.copy()
+            Tn = np.full_like(Tl, NEG)
+            for j in range(N):
+                if mdl[j] > 0:
+                    Sn[j] = max(Sn[j], Tl[j, 0] + sub[ctx[j, 0]][x])
+                    for q in range(mdl[j] - 1):
+                        Tn[j, q] = Tl[j, q + 1] + sub[ctx[j, q + 1]][x]
+            S, Tl = Sn, Tn
+            DC[:] = NEG
+        Dv = np.full(N, np.inf)                                   # "not evaluated yet"
+        changed = True
+        while changed:                                            # sweeps
+            changed = False
+            for j in range(N):
+                d = DC[j]
+                s = max(S[j], SC[j]) if has_s[j] else S[j]
+                if d != Dv[j] or s != S[j]:
+                    changed = True
+                    s = max(s, d + del_end)
+                    S[j], Dv[j] = s, d
+                    xv = max(d + del_extend, s + del_open)
+                    for dst, cls, base, sc_idx in out[j]:
+                        if sc_idx is None:
+                            DC[dst] = max(DC[dst], xv + scores[cls])
+                        else:
+                            DC[dst] = max(DC[dst], d + scores[cls])
+                            SC[dst] = max(SC[dst], s + scores[cls])
+        S_lat[pos], D_lat[pos] = S, Dv
+        if pos > 0:
+            for j in range(N):
+                for q in range(mdl[j]):
+                    Tl[j, q] = max(Tl[j, q], (S[j] + tan_dup) + length[q])
+    if local:                                                     # viterbi.cpp:171-173
+        S_lat[L, N - 1] = S_lat[L].max()
+    return S_lat, D_lat
+
+
+@pytest.mark.parametrize("mach,fa,flags", [
+    ("l4c4.json", "hello.fa", dict()),
+    ("l4c4.json", "hello.dup.fa", dict(global_=True)),
+    ("mr2l4c4.json", "hello.mr2.fa", dict(global_=True)),
+])
+def test_plan_tables_reproduce_the_oracle_lattice(oracle_mod, ref_data, mach, fa, flags):
+    import dnastore_amd as da
+    O = oracle_mod
+    path = os.path.join(ref_data, mach)
+    fm = da.FlatModel(da.Machine.fromFile(path), da.MutatorParams.fromFlags(**flags))
+    read = da.read_fastseqs(os.path.join(ref_data, fa))[0][1][:24]          # pure-Python loops: keep it short
+    orc = O.ViterbiOracle(O.Machine.from_file(path), O.MutatorParams.from_cli(**flags))
+    _, _, olat = orc.decode(read, want_lattice=True)                       # [L+1][N][lanes]
+    S_lat, D_lat = _emulate(fm, da.tokenize(read), local=not flags.get("global_", False))
+    assert np.array_equal(S_lat.view(np.uint64), np.ascontiguousarray(olat[:, :, 0]).view(np.uint64))
+    assert np.array_equal(D_lat.view(np.uint64), np.ascontiguousarray(olat[:, :, 1]).view(np.uint64))
+
+
+def test_plan_row_program_invariants(ref_data):
+    """Every state placed once, rows within capacity, null edges only into rows with an S stripe."""
+    import dnastore_amd as da
+    for mach in ("l4c4.json", "h74l4c4.json", "s16h74l4c4.json"):
+        fm = da.FlatModel(da.Machine.fromFile(os.path.join(ref_data, mach)), da.MutatorParams.fromFlags(global_=True))
+        shapes, ent, meta, n_s = fm.plan_tables()
+        lds_idx, lat_slot, T, K = fm.plan_slots()
+        N = fm.view.contents.n_states
+        assert len(set(lds_idx.tolist())) == N and lds_idx.min() >= 0 and lds_idx.max() < K * T
+        assert len(set(lat_slot.tolist())) == N
+        rows, lanes = lds_idx // T, lds_idx % T
+        assert np.array_equal(lat_slot, (rows // 2) * 2 * T + 2 * lanes + (rows & 1))
+        assert sorted(s for s in shapes[:, 1] if s >= 0) == list(range(n_s))
+        valid = (meta >> 29) & 1
+        assert int(valid.sum()) == N
+        assert ent.shape == (max(int(np.maximum(shapes[:, 0], 0).sum()), 1), T)
+        # rows the plan left empty hold no state
+        for k in range(K):
+            if shapes[k, 0] < 0:
+                assert not (rows == k).any()
