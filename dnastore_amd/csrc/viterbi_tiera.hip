@@ -111,6 +111,12 @@ __device__ __forceinline__ unsigned opaque(unsigned v) {
 constexpr double kNegInf = -__builtin_huge_val();
 constexpr double kFresh = __builtin_huge_val();   // "not evaluated in this column yet" in a D register
 
+#ifndef DNAS_NT_H
+#define DNAS_NT_H 1   // how many of the oldest history columns are streamed
+#endif
+#ifndef DNAS_NT_D
+#define DNAS_NT_D 1
+#endif
 #ifndef DNAS_LOCKSTEP
 #define DNAS_LOCKSTEP 0
 #endif
@@ -180,7 +186,10 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
       if (pairValid & (1u << m2)) {                                                              \
         dbl2 v2;                                                                                 \
         v2.x = REG[2 * m2]; v2.y = REG[2 * m2 + 1];                                              \
-        reinterpret_cast<dbl2*>(colp + (size_t)m2 * 2 * T)[tid] = v2;                            \
+        if ((lane) == 1 && DNAS_NT_D)   /* the D lane is not read again by this kernel */          \
+          __builtin_nontemporal_store(v2, reinterpret_cast<dbl2*>(colp + (size_t)m2 * 2 * T) + tid); \
+        else                                                                                     \
+          reinterpret_cast<dbl2*>(colp + (size_t)m2 * 2 * T)[tid] = v2;                          \
       }                                                                                          \
     });                                                                                          \
   }
@@ -351,7 +360,9 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
 #ifdef DNAS_DIAG_NO_HIST   // timing experiment
               dbl2 v2; v2.x = S[2 * m2]; v2.y = S[2 * m2 + 1];
 #else
-              const dbl2 v2 = reinterpret_cast<const dbl2*>(col - (size_t)i * lanes * NS + (size_t)m2 * 2 * T)[tid];
+              const dbl2* const hp = reinterpret_cast<const dbl2*>(col - (size_t)i * lanes * NS + (size_t)m2 * 2 * T) + tid;
+              // the oldest column is read for the last time: stream it past the caches
+              const dbl2 v2 = (DNAS_NT_H && i >= D_ - DNAS_NT_H) ? __builtin_nontemporal_load(hp) : *hp;
 #endif
               sh[2 * m2 - k0][i - 1] = v2.x;
               sh[2 * m2 + 1 - k0][i - 1] = v2.y;
