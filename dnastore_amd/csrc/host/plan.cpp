@@ -16,7 +16,7 @@ constexpr int kMaxEntries = 40;   // entry registers per thread the kernel can a
 constexpr int kWalk = 30;         // length of the walks the sweep estimate looks at
 
 struct Edge { int src, dst, sc, base, isNull; };
-typedef std::array<int, 2> Type;  // out-edges, has null in-edges
+typedef std::array<int, 3> Type;  // out-edges, has null in-edges, not plain (some out-edge is a null edge or carries a score)
 
 }  // namespace
 
@@ -58,7 +58,9 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
   for (int j = 0; j < N; ++j) {
     int hasS = 0;
     for (int e : inOf[j]) hasS |= edges[e].isNull;
-    type[j] = Type{(int)outOf[j].size(), hasS};
+    int notPlain = 0;
+    for (int e : outOf[j]) notPlain |= (edges[e].isNull || edges[e].sc != 0) ? 1 : 0;
+    type[j] = Type{(int)outOf[j].size(), hasS, notPlain};
     maxOut = std::max(maxOut, type[j][0]);
     nNullDest += hasS;
   }
@@ -111,7 +113,7 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
     std::vector<unsigned> admits(types.size(), 0), own(types.size(), 0);
     for (size_t t = 0; t < types.size(); ++t)
       for (int k = 0; k < K; ++k)
-        if (types[t][0] <= caps[k][0] && types[t][1] <= caps[k][1]) {
+        if (types[t][0] <= caps[k][0] && types[t][1] <= caps[k][1] && types[t][2] <= caps[k][2]) {
           admits[t] |= 1u << k;
           if (types[t][1] == caps[k][1]) own[t] |= 1u << k;     // S rows are kept for the states that need them
         }
@@ -159,13 +161,15 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
     return true;
   };
   auto score = [&](const std::vector<int>& rows, int* readsOut, int* backOut, int* entriesOut) -> double {
-    std::vector<Type> shape(K, Type{0, 0});
+    std::vector<Type> shape(K, Type{0, 0, 0});
     for (int j = 0; j < N; ++j)
-      for (int q = 0; q < 2; ++q) shape[rows[j]][q] = std::max(shape[rows[j]][q], type[j][q]);
+      for (int q = 0; q < 3; ++q) shape[rows[j]][q] = std::max(shape[rows[j]][q], type[j][q]);
     std::vector<char> inUse(K, 0);
     for (int j = 0; j < N; ++j) inUse[rows[j]] = 1;
     int reads = 0, entries = 0;
-    for (int k = 0; k < K; ++k) if (inUse[k]) { reads += 1 + shape[k][1]; entries += shape[k][0]; }
+    double offerCost = 0;   // an entry of a plain row is offered with a third of the instructions
+    for (int k = 0; k < K; ++k)
+      if (inUse[k]) { reads += 1 + shape[k][1]; entries += shape[k][0]; offerCost += shape[k][2] ? shape[k][0] : 0.4 * shape[k][0]; }
     std::vector<int> f(N, 0), g(N);
     for (int h = 0; h < kWalk; ++h) {
       std::fill(g.begin(), g.end(), 0);
@@ -179,7 +183,7 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
     for (int v : f) back = std::max(back, v);
     *readsOut = reads; *backOut = back; *entriesOut = entries;
     // a sweep costs its accumulator reads plus, where cells grew, one offer per entry
-    return (double)(reads + entries + 10) * (double)(back + 1);
+    return ((double)reads + offerCost + 10.0) * (double)(back + 1);
   };
   auto ldsNeed = [&](int nS) { return (size_t)(p.NS + nS * T + 8 + 28 + T / 64 + (T / 64 + 2) / 2 + 1) * sizeof(double); };
 
@@ -187,10 +191,14 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
   std::vector<Type> bestCaps;
   {
     // out-degrees in ascending order, per kind, for the quantile shapes
-    std::vector<int> outS, outP;
-    for (int j = 0; j < N; ++j) (type[j][1] ? outS : outP).push_back(type[j][0]);
+    std::vector<int> outS, outP, outPlainP;   // outPlainP: plain states without null in-edges
+    for (int j = 0; j < N; ++j) {
+      (type[j][1] ? outS : outP).push_back(type[j][0]);
+      if (!type[j][1] && !type[j][2]) outPlainP.push_back(type[j][0]);
+    }
     std::sort(outS.begin(), outS.end());
     std::sort(outP.begin(), outP.end());
+    std::sort(outPlainP.begin(), outPlainP.end());
     const int minS = (nNullDest + T - 1) / T;
     double bestScore = -1;
     std::string why = "no row program fits";
@@ -201,7 +209,8 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
       if (ldsNeed(nS) > kTierALdsLimit) { why = "LDS working set " + std::to_string(ldsNeed(nS)) + " B exceeds one CU"; continue; }
       if ((size_t)KU * T < (size_t)N) continue;
       for (int groups = 1; groups <= std::max(1, std::min(3, nS)); ++groups) {
-        for (int ascending = 0; ascending < 2; ++ascending) {
+        for (int ascending = 0; ascending < 2; ++ascending)
+        for (int plainRows = 0; plainRows < 2; ++plainRows) {
           // kinds: the S rows in `groups` runs spread evenly over the program
           std::vector<int> isS(K, 0);
           for (int g = 0, left = nS; g < groups && nS > 0; ++g) {
@@ -212,7 +221,7 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
           }
           if (std::accumulate(isS.begin(), isS.end(), 0) != nS) continue;   // runs collided
           std::vector<Type> caps(K);
-          int seenS = 0, seenP = 0;
+          int seenS = 0, seenP = 0, nPlainRows = 0;
           for (int k = 0; k < K; ++k) {
             const std::vector<int>& sorted = isS[k] ? outS : outP;
             int& seen = isS[k] ? seenS : seenP;
@@ -221,7 +230,14 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
               const size_t q = std::min(sorted.size() - 1, (size_t)(seen + 1) * T - 1);
               cap = (size_t)(seen + 1) * T >= sorted.size() ? maxOut : sorted[q];
             }
-            caps[k] = k < KU ? Type{cap, isS[k]} : Type{-1, -1};   // closed rows admit nothing
+            // plain rows: rows without S cells that only admit plain states, as long as there are enough
+            // plain states of that out-degree to fill them
+            int generic = 1;
+            if (plainRows && !isS[k] && k < KU) {
+              const size_t have = (size_t)(std::upper_bound(outPlainP.begin(), outPlainP.end(), cap) - outPlainP.begin());
+              if (have >= (size_t)(nPlainRows + 1) * T) { generic = 0; ++nPlainRows; }
+            }
+            caps[k] = k < KU ? Type{cap, isS[k], generic} : Type{-1, -1, -1};   // closed rows admit nothing
             ++seen;
           }
           std::vector<int> rows;
@@ -229,11 +245,12 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
           int reads = 0, back = 0, entries = 0;
           const double sc = score(rows, &reads, &back, &entries);
           if (getenv("DNAS_PLAN_DEBUG"))
-            fprintf(stderr, "plan candidate: rows %d S-rows %d groups %d ascending %d -> reads %d entries %d back %d score %.0f\n", KU, nS,
-                    groups, ascending, reads, entries, back, sc);
+            fprintf(stderr, "plan candidate: rows %d S-rows %d groups %d ascending %d plain %d -> reads %d entries %d back %d score %.0f\n", KU, nS,
+                    groups, ascending, plainRows, reads, entries, back, sc);
           if (const char* pick = getenv("DNAS_PLAN_PICK")) {   // experiments: "rows,S-rows,groups,ascending"
-            int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-            if (sscanf(pick, "%d,%d,%d,%d", &a0, &a1, &a2, &a3) == 4 && (a0 != KU || a1 != nS || a2 != groups || a3 != ascending)) continue;
+            int a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+            if (sscanf(pick, "%d,%d,%d,%d,%d", &a0, &a1, &a2, &a3, &a4) == 5 &&
+                (a0 != KU || a1 != nS || a2 != groups || a3 != ascending || a4 != plainRows)) continue;
           }
           if (entries > kMaxEntries) { why = "row shapes need " + std::to_string(entries) + " entry registers per thread"; continue; }
           if (bestScore < 0 || sc < bestScore) {
@@ -311,18 +328,24 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
   }
 
   // row shapes as used, S stripes
-  p.rows.assign(K, RowShape{0, -1});
+  p.rows.assign(K, RowShape{0, -1, -1, -2});   // kind / cls: -1 / -2 = no entry seen yet
   std::vector<int> needS(K, 0);
   long real = 0;
   for (int j = 0; j < N; ++j) {
     RowShape& r = p.rows[rowOfState[j]];
     r.nOut = std::max(r.nOut, type[j][0]);
+    for (int e : outOf[j]) {
+      const int kind = edges[e].isNull ? 2 : 1;
+      r.kind = r.kind < 0 ? kind : (r.kind == kind ? kind : 0);
+      r.cls = r.cls == -2 ? edges[e].sc : (r.cls == edges[e].sc ? r.cls : -1);
+    }
     needS[rowOfState[j]] |= type[j][1];
     real += type[j][0];
   }
   p.nSRows = 0;
   for (int k = 0; k < K; ++k) if (needS[k]) p.rows[k].sIdx = p.nSRows++;
   for (int k = 0; k < K; ++k) if (rowMembers[k].empty()) p.rows[k].nOut = -1;   // the kernel skips the row
+  for (RowShape& r : p.rows) { if (r.kind < 0) r.kind = 0; if (r.cls == -2) r.cls = -1; }
   p.ldsBytes = ldsNeed(p.nSRows);
   if (p.ldsBytes > kTierALdsLimit) return no("LDS working set " + std::to_string(p.ldsBytes) + " B exceeds one CU");
   int nEnt = 0;
@@ -383,7 +406,7 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
   std::ostringstream rows, defs;
   for (int k = 0; k < K; ++k) {
     if (k) rows << ",";
-    rows << "{" << p.rows[k].nOut << "," << p.rows[k].sIdx << "}";
+    rows << "{" << p.rows[k].nOut << "," << p.rows[k].sIdx << "," << p.rows[k].kind << "," << p.rows[k].cls << "}";
   }
   defs << "-DDNAS_T=" << T << "\n-DDNAS_K=" << K << "\n-DDNAS_D=" << D << "\n-DDNAS_NS=" << p.NS << "\n-DDNAS_SROWS=" << p.nSRows
        << "\n-DDNAS_NCLS=" << p.nClasses << "\n-DDNAS_ROWS=" << rows.str();

@@ -23,7 +23,8 @@
 //
 // Compile-time parameters (-D):  DNAS_T threads, DNAS_K rows, DNAS_D dup lanes,
 //   DNAS_NS slots (= K*T), DNAS_SROWS S stripes, DNAS_NCLS distinct edge scores,
-//   DNAS_ROWS  brace list of {out-edge entries (-1: row left empty), S stripe or -1} per row.
+//   DNAS_ROWS  brace list of {out-edge entries (-1: row left empty), S stripe or -1, kind, cls} per row;
+//              what all entries of a row have in common is not decoded per lane.
 #ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>   // hiprtc provides the device runtime implicitly
 #endif
@@ -32,7 +33,7 @@
 #error "compile with -DDNAS_T= -DDNAS_K= -DDNAS_D= -DDNAS_NS= -DDNAS_SROWS= -DDNAS_NCLS= -DDNAS_ROWS="
 #endif
 
-struct RowShape { int nOut, sIdx; };
+struct RowShape { int nOut, sIdx, kind, cls; };   // kind: 1 emit edges only, 2 null edges only, 0 both; cls: common score class or -1
 constexpr RowShape kRows[DNAS_K] = {DNAS_ROWS};
 
 constexpr bool rowLive(int k) { return kRows[k].nOut >= 0; }      // nOut -1: the plan left the row empty
@@ -154,6 +155,13 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
     else if constexpr (DNAS_NCLS == 2) return cls ? v + a.score[1] : v;
     else return v + ldsRead(ldsB, kTabBase + cls * 8);
   };
+  // ... of an entry of row k: the row's common class is a compile-time constant
+  auto withScoreRow = [&](auto kc, double v, unsigned en) -> double {
+    constexpr int c = kRows[kc.value].cls;
+    if constexpr (c == 0) return v;
+    else if constexpr (c > 0) return v + a.score[c];
+    else return withScore(v, ENT_CLS(en));
+  };
   // own accumulators: byte addresses
   const unsigned ownB = (unsigned)tid * 8u;
 #define DC_OWN(k) (ownB + (unsigned)kDCBase + (unsigned)(k) * T * 8u)
@@ -217,8 +225,9 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
         if (rowLive(k) && S[k] > kNegInf) {
           static_for<0, rowOut(k)>([&](auto ec) {
             const unsigned en = opaque(E[o + ec.value]);
-            if (ENT_EMIT(en))
-              ldsMax(ldsB, ENT_DC(en), (withScore(S[k], ENT_CLS(en)) + a.noGap) + ldsRead(ldsB, subRow + ENT_BASE32(en)));
+            if constexpr (kRows[k].kind == 2) return;             // no emit edge in this row
+            const bool emit = kRows[k].kind == 1 ? ENT_VALID(en) : ENT_EMIT(en);
+            if (emit) ldsMax(ldsB, ENT_DC(en), (withScoreRow(kc, S[k], en) + a.noGap) + ldsRead(ldsB, subRow + ENT_BASE32(en)));
           });
         }
       });
@@ -285,11 +294,16 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
             static_for<0, rowOut(k)>([&](auto ec) {
               const unsigned en = opaque(E[o + ec.value]);
               if (ENT_VALID(en)) {
-                if (ENT_EMIT(en)) {
-                  ldsMax(ldsB, ENT_DC(en), withScore(xv, ENT_CLS(en)));
-                } else {                                               // viterbi.cpp:137-151
-                  ldsMax(ldsB, ENT_DC(en), withScore(d, ENT_CLS(en)));
-                  ldsMax(ldsB, ENT_SC(en), withScore(s, ENT_CLS(en)));
+                if constexpr (kRows[k].kind == 1) {
+                  ldsMax(ldsB, ENT_DC(en), withScoreRow(kc, xv, en));
+                } else if constexpr (kRows[k].kind == 2) {            // viterbi.cpp:137-151
+                  ldsMax(ldsB, ENT_DC(en), withScoreRow(kc, d, en));
+                  ldsMax(ldsB, ENT_SC(en), withScoreRow(kc, s, en));
+                } else if (ENT_EMIT(en)) {
+                  ldsMax(ldsB, ENT_DC(en), withScoreRow(kc, xv, en));
+                } else {
+                  ldsMax(ldsB, ENT_DC(en), withScoreRow(kc, d, en));
+                  ldsMax(ldsB, ENT_SC(en), withScoreRow(kc, s, en));
                 }
               }
             });
