@@ -17,6 +17,7 @@ struct DevModel {
   const int32_t* eoutPtr; const int32_t* eoutDst;
   const int32_t* noutPtr; const int32_t* noutDst;
   const int32_t* slotOf;  // tier A: state -> lattice slot (nullptr: identity)
+  const int32_t* einSlot; const int32_t* ninSlot;   // lattice slot of every in-edge's source (saves the traceback a dependent load)
   const uint8_t* mdl;   // [N]
   const uint8_t* ctx;   // [N*D]
   double noGap, delOpen, delExtend, delEnd, tanDup;

@@ -158,6 +158,14 @@ extern "C" int dnas_model_create(const dnas_flat_model* fm, int device_id, size_
   if (hipMalloc((void**)&m->dRounds, 8 * sizeof(unsigned long long)) != hipSuccess)
     return bail(dnas::fail(DNAS_E_DEVICE, "hipMalloc failed"));
   // ---- tier A: specialise the register/LDS-resident kernel for this machine
+  auto uploadEdgeSlots = [&](const int32_t* slotOf) -> int {   // after the tier (and with it the slot map) is known
+    std::vector<int32_t> es((size_t)std::max(fm->n_emit, 1)), ns((size_t)std::max(fm->n_null, 1));
+    for (int e = 0; e < fm->n_emit; ++e) es[(size_t)e] = slotOf ? slotOf[fm->ein_src[e]] : fm->ein_src[e];
+    for (int e = 0; e < fm->n_null; ++e) ns[(size_t)e] = slotOf ? slotOf[fm->nin_src[e]] : fm->nin_src[e];
+    int r = upload(m, es.data(), es.size(), &d.einSlot);
+    if (r == DNAS_OK) r = upload(m, ns.data(), ns.size(), &d.ninSlot);
+    return r;
+  };
   {
     const char* force = getenv("DNAS_TIER");
     if (force && (force[0] == 'B' || force[0] == 'b')) {
@@ -203,6 +211,7 @@ extern "C" int dnas_model_create(const dnas_flat_model* fm, int device_id, size_
       }
     }
   }
+  if ((rc = uploadEdgeSlots(m->tier == 1 ? m->plan.slotOf.data() : nullptr)) != DNAS_OK) return bail(rc);
   size_t freeB = 0, totalB = 0;
   if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return bail(dnas::fail(DNAS_E_DEVICE, "hipMemGetInfo failed"));
   m->arenaCap = arena_bytes ? arena_bytes : (size_t)((double)freeB * 0.6);

@@ -87,6 +87,24 @@ __device__ __forceinline__ double lattice_cell(const DevModel& m, const double* 
   return v;
 }
 
+// the same with the lattice slot already known
+__device__ __forceinline__ double cell_at(const DevModel& m, const double* __restrict__ lat, const uint8_t* __restrict__ seq,
+                                          int st, int slot, int ps, int ln) {
+  const size_t stride = (size_t)m.Npad;
+  if (ln < 2 || m.storedLanes > 2) return lat[((size_t)ps * m.storedLanes + (size_t)ln) * stride + (size_t)slot];
+  const int k = ln - 2, mdl = m.mdl[st];
+  if (ps < 1 || k >= mdl) return kNegInf;
+  const uint8_t* ctx = m.ctx + (size_t)st * m.D;
+  int I = mdl - 1 - k;
+  if (ps - 1 < I) I = ps - 1;
+  double v = (lat[((size_t)(ps - I) * 2) * stride + (size_t)slot] + m.tanDup) + m.len[k + I];
+  for (int i = I - 1; i >= 0; --i) {
+    const int p = ps - i, q = k + i;
+    v = dmax(v + m.sub[ctx[q + 1] * 4 + seq[p - 1]], (lat[((size_t)p * 2) * stride + (size_t)slot] + m.tanDup) + m.len[q]);
+  }
+  return v;
+}
+
 }  // namespace
 
 // Test/diagnostic aid: the full (D+2)-lane lattice of one read in reference state order,
@@ -241,53 +259,102 @@ viterbi_traceback_kernel(DevModel m, const uint8_t* __restrict__ bases, const ui
   }
   int state = N - 1, pos = L, mut = 0;
   int bestState = 0, bestPos = 0, bestMut = 0;
-  double best;
+  double best, bestCell = kNegInf;
   bool found;
   uint8_t bestIn;
   uint8_t status = 0;
+  double curCell;   // the lattice cell the walk stands on (read when it was chosen as a candidate)
 
+  // A step's candidates are independent loads: they are gathered CH at a time -- edge fields, then
+  // the cells, then the compares in the reference's order (first strictly greater wins) -- so that a
+  // step costs a few memory latencies instead of one chain per candidate.
+  constexpr int CH = 4;
+  int cSt[CH], cSlot[CH], cPs[CH], cLn[CH];
+  double cTr[CH];
+  uint8_t cIn[CH];
 #define INIT_BEST() { best = kNegInf; found = false; bestIn = 0; }
-#define UPDATE_BEST(ss, pp, mm, trans, insym) { \
-    const double sc_ = CELL(ss, pp, mm) + (trans); \
-    if (sc_ > best) { best = sc_; bestState = (ss); bestPos = (pp); bestMut = (mm); bestIn = (insym); found = true; } }
+#define FLUSH(cnt) { \
+    double v_[CH]; \
+    _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) v_[i_] = i_ < (cnt) ? cell_at(m, lat, seq, cSt[i_], cSlot[i_], cPs[i_], cLn[i_]) : kNegInf; \
+    _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) if (i_ < (cnt)) { \
+      const double sc_ = v_[i_] + cTr[i_]; \
+      if (sc_ > best) { best = sc_; bestCell = v_[i_]; bestState = cSt[i_]; bestPos = cPs[i_]; bestMut = cLn[i_]; bestIn = cIn[i_]; found = true; } } }
+#define SET(i, st_, slot_, ps_, ln_, tr_, in_) { cSt[i] = (st_); cSlot[i] = (slot_); cPs[i] = (ps_); cLn[i] = (ln_); cTr[i] = (tr_); cIn[i] = (in_); }
 #define CHECK_BEST() { \
-    const double exp_ = CELL(state, pos, mut); \
-    const double den_ = fabs(exp_) < 1e-6 ? 1. : exp_; \
-    if (!(fabs((best - exp_) / den_) < 1e-6) || !found) { status = 3; break; } \
-    state = bestState; pos = bestPos; mut = bestMut; }
+    const double den_ = fabs(curCell) < 1e-6 ? 1. : curCell; \
+    if (!(fabs((best - curCell) / den_) < 1e-6) || !found) { status = 3; break; } \
+    state = bestState; pos = bestPos; mut = bestMut; curCell = bestCell; }
+  const int32_t* slotOf = m.slotOf;
+#define SLOT(st) (slotOf ? slotOf[st] : (st))
 
   do {  // single-pass block so CHECK_BEST can break out on failure
     INIT_BEST();
-    if (m.local) { for (int s = 0; s < N; ++s) UPDATE_BEST(s, L, 0, 0., 0); }
-    else UPDATE_BEST(N - 1, L, 0, 0., 0);
+    curCell = CELL(N - 1, L, 0);
+    if (m.local) {
+      for (int s0 = 0; s0 < N; s0 += CH) {
+        _Pragma("unroll") for (int i = 0; i < CH; ++i) if (s0 + i < N) SET(i, s0 + i, SLOT(s0 + i), L, 0, 0., 0)
+        FLUSH(N - s0 < CH ? N - s0 : CH)
+      }
+    } else {
+      SET(0, N - 1, SLOT(N - 1), L, 0, 0., 0)
+      FLUSH(1)
+    }
     CHECK_BEST();
 
     while (pos >= 0 && state > 0) {
       const int mdl = m.mdl[state];
       const uint8_t* ctx = m.ctx + (size_t)state * D_;
+      const int ownSlot = SLOT(state);
       INIT_BEST();
       if (mut == 0) {
         if (pos > 0) {
           const int x = seq[pos - 1];
-          for (int e = m.einPtr[state]; e < m.einPtr[state + 1]; ++e)
-            UPDATE_BEST(m.einSrc[e], pos - 1, 0, (m.einScore[e] + m.noGap) + m.sub[m.einBase[e] * 4 + x], m.einIn[e]);
+          const int e1 = m.einPtr[state + 1];
+          for (int e0 = m.einPtr[state]; e0 < e1; e0 += CH) {
+            _Pragma("unroll") for (int i = 0; i < CH; ++i) if (e0 + i < e1)
+              SET(i, m.einSrc[e0 + i], m.einSlot[e0 + i], pos - 1, 0, (m.einScore[e0 + i] + m.noGap) + m.sub[m.einBase[e0 + i] * 4 + x], m.einIn[e0 + i])
+            FLUSH(e1 - e0 < CH ? e1 - e0 : CH)
+          }
         }
-        for (int e = m.ninPtr[state]; e < m.ninPtr[state + 1]; ++e)
-          UPDATE_BEST(m.ninSrc[e], pos, 0, m.ninScore[e], m.ninIn[e]);
-        UPDATE_BEST(state, pos, 1, m.delEnd, 0);
-        if (mdl > 0 && pos > 0) UPDATE_BEST(state, pos - 1, 2, m.sub[ctx[0] * 4 + seq[pos - 1]], 0);
-        if (pos == 0 && m.local) UPDATE_BEST(0, 0, 0, 0., 0);
+        {
+          const int e1 = m.ninPtr[state + 1];
+          for (int e0 = m.ninPtr[state]; e0 < e1; e0 += CH) {
+            _Pragma("unroll") for (int i = 0; i < CH; ++i) if (e0 + i < e1)
+              SET(i, m.ninSrc[e0 + i], m.ninSlot[e0 + i], pos, 0, m.ninScore[e0 + i], m.ninIn[e0 + i])
+            FLUSH(e1 - e0 < CH ? e1 - e0 : CH)
+          }
+        }
+        int c = 0;
+        SET(0, state, ownSlot, pos, 1, m.delEnd, 0)
+        c = 1;
+        if (mdl > 0 && pos > 0) { SET(1, state, ownSlot, pos - 1, 2, m.sub[ctx[0] * 4 + seq[pos - 1]], 0) c = 2; }
+        if (pos == 0 && m.local) {
+          if (c == 1) SET(1, 0, SLOT(0), 0, 0, 0., 0) else SET(2, 0, SLOT(0), 0, 0, 0., 0)
+          ++c;
+        }
+        FLUSH(c)
       } else if (mut == 1) {
-        for (int e = m.einPtr[state]; e < m.einPtr[state + 1]; ++e) {
-          UPDATE_BEST(m.einSrc[e], pos, 1, m.einScore[e] + m.delExtend, m.einIn[e]);
-          UPDATE_BEST(m.einSrc[e], pos, 0, m.einScore[e] + m.delOpen, m.einIn[e]);
+        const int e1 = m.einPtr[state + 1];
+        for (int e0 = m.einPtr[state]; e0 < e1; e0 += CH / 2) {
+          _Pragma("unroll") for (int i = 0; i < CH / 2; ++i) if (e0 + i < e1) {
+            SET(2 * i, m.einSrc[e0 + i], m.einSlot[e0 + i], pos, 1, m.einScore[e0 + i] + m.delExtend, m.einIn[e0 + i])
+            SET(2 * i + 1, m.einSrc[e0 + i], m.einSlot[e0 + i], pos, 0, m.einScore[e0 + i] + m.delOpen, m.einIn[e0 + i])
+          }
+          FLUSH(2 * (e1 - e0 < CH / 2 ? e1 - e0 : CH / 2))
         }
-        for (int e = m.ninPtr[state]; e < m.ninPtr[state + 1]; ++e)
-          UPDATE_BEST(m.ninSrc[e], pos, 1, m.ninScore[e], m.ninIn[e]);
+        const int n1 = m.ninPtr[state + 1];
+        for (int e0 = m.ninPtr[state]; e0 < n1; e0 += CH) {
+          _Pragma("unroll") for (int i = 0; i < CH; ++i) if (e0 + i < n1)
+            SET(i, m.ninSrc[e0 + i], m.ninSlot[e0 + i], pos, 1, m.ninScore[e0 + i], m.ninIn[e0 + i])
+          FLUSH(n1 - e0 < CH ? n1 - e0 : CH)
+        }
       } else {
         const int k = mut - 2;
-        if (k < mdl - 1) UPDATE_BEST(state, pos - 1, 2 + k + 1, m.sub[ctx[k + 1] * 4 + seq[pos - 1]], 0);
-        UPDATE_BEST(state, pos, 0, m.tanDup + m.len[k], 0);
+        int c = 0;
+        if (k < mdl - 1) { SET(0, state, ownSlot, pos - 1, 2 + k + 1, m.sub[ctx[k + 1] * 4 + seq[pos - 1]], 0) c = 1; }
+        if (c == 0) SET(0, state, ownSlot, pos, 0, m.tanDup + m.len[k], 0) else SET(1, state, ownSlot, pos, 0, m.tanDup + m.len[k], 0)
+        ++c;
+        FLUSH(c)
       }
       CHECK_BEST();
       if (bestIn) {  // trace.push_front (viterbi.cpp:299-300): fill the slot from its end
@@ -298,7 +365,9 @@ viterbi_traceback_kernel(DevModel m, const uint8_t* __restrict__ bases, const ui
   } while (false);
 #undef CELL
 #undef INIT_BEST
-#undef UPDATE_BEST
+#undef FLUSH
+#undef SET
+#undef SLOT
 #undef CHECK_BEST
 
   if (status == 0 && n > cap) status = 2;  // DNAS_READ_OUT_OVERFLOW
