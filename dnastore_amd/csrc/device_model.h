@@ -3,7 +3,7 @@
 #pragma once
 #include <stdint.h>
 
-constexpr int kFillThreads = 512;   // work-group size of viterbi_fill_kernel (8 waves)
+constexpr int kFillThreads = 1024;  // work-group size of viterbi_fill_kernel (16 waves: one work-group fills a CU)
 constexpr int kTraceThreads = 512;  // independent reads per traceback block: a whole batch sits on ONE CU (see runtime.hip)
 constexpr int kMaxLen = 32;         // pLen entries (dnas_mutator_params.p_len)
 
