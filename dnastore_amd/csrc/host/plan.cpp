@@ -60,6 +60,7 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
     for (int e : inOf[j]) hasS |= edges[e].isNull;
     int notPlain = 0;
     for (int e : outOf[j]) notPlain |= (edges[e].isNull || edges[e].sc != 0) ? 1 : 0;
+    if (outOf[j].empty()) notPlain = 1;   // would leave an empty entry in an otherwise full plain row
     type[j] = Type{(int)outOf[j].size(), hasS, notPlain};
     maxOut = std::max(maxOut, type[j][0]);
     nNullDest += hasS;
@@ -263,6 +264,51 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
     if (bestScore < 0) return no(why);
   }
 
+  // A handful of odd states can spoil what the entries of a row have in common (its score class, emit /
+  // null kind): move such minorities (at most 2 % of a row) to a row that admits them and is mixed anyway.
+  {
+    auto clsOf = [&](int j) { int c = -2; for (int e : outOf[j]) c = c == -2 ? edges[e].sc : (c == edges[e].sc ? c : -1); return c; };
+    auto kindOf = [&](int j) { int k = -1; for (int e : outOf[j]) { const int q = edges[e].isNull ? 2 : 1; k = k < 0 ? q : (k == q ? q : 0); } return k; };
+    for (int attr = 0; attr < 2; ++attr) {
+      std::vector<int> fill(K, 0);
+      for (int j = 0; j < N; ++j) ++fill[rowOfState[j]];
+      // what each row has in common right now (-1 / 0: mixed), per attribute
+      auto common = [&](int k) {
+        int c = -2;
+        for (int j = 0; j < N; ++j)
+          if (rowOfState[j] == k && !outOf[j].empty()) {
+            const int v = attr == 0 ? clsOf(j) : kindOf(j);
+            c = c == -2 ? v : (c == v ? c : (attr == 0 ? -1 : 0));
+          }
+        return c;
+      };
+      for (int k = 0; k < K; ++k) {
+        std::map<int, std::vector<int>> byVal;
+        for (int j = 0; j < N; ++j)
+          if (rowOfState[j] == k && !outOf[j].empty()) byVal[attr == 0 ? clsOf(j) : kindOf(j)].push_back(j);
+        if (byVal.size() < 2) continue;
+        size_t most = 0, total = 0;
+        for (const auto& kv : byVal) { most = std::max(most, kv.second.size()); total += kv.second.size(); }
+        if (total - most > (size_t)T / 50) continue;
+        for (const auto& kv : byVal) {
+          if (kv.second.size() == most) continue;
+          for (int j : kv.second) {
+            for (int k2 = 0; k2 < K; ++k2) {
+              if (k2 == k || fill[k2] >= T) continue;
+              const Type& c2 = bestCaps[k2];
+              if (type[j][0] > c2[0] || type[j][1] > c2[1] || type[j][2] > c2[2]) continue;
+              const int have = common(k2);
+              const int mine = attr == 0 ? clsOf(j) : kindOf(j);
+              if (!(have == (attr == 0 ? -1 : 0) || have == mine || have == -2)) continue;   // would spoil k2
+              rowOfState[j] = k2; --fill[k]; ++fill[k2];
+              break;
+            }
+          }
+        }
+      }
+    }
+  }
+
   // Lane placement inside each row.  Two goals.  (1) The waves of a work-group sweep without a
   // barrier and drift apart, so an edge into a later row is only CERTAIN to be relaxed in the
   // same sweep when source and destination belong to the same wave (a wave runs its rows in
@@ -328,7 +374,7 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
   }
 
   // row shapes as used, S stripes
-  p.rows.assign(K, RowShape{0, -1, -1, -2});   // kind / cls: -1 / -2 = no entry seen yet
+  p.rows.assign(K, RowShape{0, -1, -1, -2, 0});   // kind / cls: -1 / -2 = no entry seen yet
   std::vector<int> needS(K, 0);
   long real = 0;
   for (int j = 0; j < N; ++j) {
@@ -346,6 +392,11 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
   for (int k = 0; k < K; ++k) if (needS[k]) p.rows[k].sIdx = p.nSRows++;
   for (int k = 0; k < K; ++k) if (rowMembers[k].empty()) p.rows[k].nOut = -1;   // the kernel skips the row
   for (RowShape& r : p.rows) { if (r.kind < 0) r.kind = 0; if (r.cls == -2) r.cls = -1; }
+  for (int k = 0; k < K; ++k) {
+    bool full = (int)rowMembers[k].size() == T;
+    for (int j : rowMembers[k]) full = full && type[j][0] == p.rows[k].nOut;
+    p.rows[k].full = full ? 1 : 0;
+  }
   p.ldsBytes = ldsNeed(p.nSRows);
   if (p.ldsBytes > kTierALdsLimit) return no("LDS working set " + std::to_string(p.ldsBytes) + " B exceeds one CU");
   int nEnt = 0;
@@ -406,7 +457,7 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
   std::ostringstream rows, defs;
   for (int k = 0; k < K; ++k) {
     if (k) rows << ",";
-    rows << "{" << p.rows[k].nOut << "," << p.rows[k].sIdx << "," << p.rows[k].kind << "," << p.rows[k].cls << "}";
+    rows << "{" << p.rows[k].nOut << "," << p.rows[k].sIdx << "," << p.rows[k].kind << "," << p.rows[k].cls << "," << p.rows[k].full << "}";
   }
   defs << "-DDNAS_T=" << T << "\n-DDNAS_K=" << K << "\n-DDNAS_D=" << D << "\n-DDNAS_NS=" << p.NS << "\n-DDNAS_SROWS=" << p.nSRows
        << "\n-DDNAS_NCLS=" << p.nClasses << "\n-DDNAS_ROWS=" << rows.str();

@@ -22,8 +22,9 @@ namespace dnas {
 
 // per row: out-edge entries per state (-1: row left empty), the row's S stripe (-1: no state of the row has
 // null in-edges), and what all entries of the row have in common, which the kernel then does not decode per
-// lane: kind 1 = emit edges only, 2 = null edges only, 0 = both; cls = the common score class or -1
-struct RowShape { int nOut, sIdx, kind, cls; };
+// lane: kind 1 = emit edges only, 2 = null edges only, 0 = both; cls = the common score class or -1;
+// full = every lane of the row holds a state with exactly nOut out-edges (no entry is empty)
+struct RowShape { int nOut, sIdx, kind, cls, full; };
 
 struct TierAPlan {
   bool ok = false;

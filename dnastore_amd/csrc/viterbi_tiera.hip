@@ -23,7 +23,7 @@
 //
 // Compile-time parameters (-D):  DNAS_T threads, DNAS_K rows, DNAS_D dup lanes,
 //   DNAS_NS slots (= K*T), DNAS_SROWS S stripes, DNAS_NCLS distinct edge scores,
-//   DNAS_ROWS  brace list of {out-edge entries (-1: row left empty), S stripe or -1, kind, cls} per row;
+//   DNAS_ROWS  brace list of {out-edge entries (-1: row left empty), S stripe or -1, kind, cls, full} per row;
 //              what all entries of a row have in common is not decoded per lane.
 #ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>   // hiprtc provides the device runtime implicitly
@@ -33,7 +33,7 @@
 #error "compile with -DDNAS_T= -DDNAS_K= -DDNAS_D= -DDNAS_NS= -DDNAS_SROWS= -DDNAS_NCLS= -DDNAS_ROWS="
 #endif
 
-struct RowShape { int nOut, sIdx, kind, cls; };   // kind: 1 emit edges only, 2 null edges only, 0 both; cls: common score class or -1
+struct RowShape { int nOut, sIdx, kind, cls, full; };   // kind: 1 emit edges only, 2 null edges only, 0 both; cls: common score class or -1; full: no empty entry
 constexpr RowShape kRows[DNAS_K] = {DNAS_ROWS};
 
 constexpr bool rowLive(int k) { return kRows[k].nOut >= 0; }      // nOut -1: the plan left the row empty
@@ -226,7 +226,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
           static_for<0, rowOut(k)>([&](auto ec) {
             const unsigned en = opaque(E[o + ec.value]);
             if constexpr (kRows[k].kind == 2) return;             // no emit edge in this row
-            const bool emit = kRows[k].kind == 1 ? ENT_VALID(en) : ENT_EMIT(en);
+            const bool emit = kRows[k].kind == 1 ? (kRows[k].full != 0 || ENT_VALID(en)) : ENT_EMIT(en);
             if (emit) ldsMax(ldsB, ENT_DC(en), (withScoreRow(kc, S[k], en) + a.noGap) + ldsRead(ldsB, subRow + ENT_BASE32(en)));
           });
         }
@@ -293,7 +293,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
             const double xv = dmax(d + a.delExtend, s + a.delOpen);    // viterbi.cpp:124
             static_for<0, rowOut(k)>([&](auto ec) {
               const unsigned en = opaque(E[o + ec.value]);
-              if (ENT_VALID(en)) {
+              if (kRows[k].full != 0 || ENT_VALID(en)) {
                 if constexpr (kRows[k].kind == 1) {
                   ldsMax(ldsB, ENT_DC(en), withScoreRow(kc, xv, en));
                 } else if constexpr (kRows[k].kind == 2) {            // viterbi.cpp:137-151
