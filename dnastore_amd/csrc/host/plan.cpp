@@ -16,7 +16,8 @@ constexpr int kMaxEntries = 40;   // entry registers per thread the kernel can a
 constexpr int kWalk = 30;         // length of the walks the sweep estimate looks at
 
 struct Edge { int src, dst, sc, base, isNull; };
-typedef std::array<int, 3> Type;  // out-edges, has null in-edges, not plain (some out-edge is a null edge or carries a score)
+typedef std::array<int, 4> Type;  // out-edges, has null in-edges, not plain (some out-edge is a null edge or carries a score),
+                                  // score class of the out-edges (4: they differ, 7: no out-edge) -- in a row's caps: the mask of classes it admits
 
 }  // namespace
 
@@ -61,7 +62,9 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
     int notPlain = 0;
     for (int e : outOf[j]) notPlain |= (edges[e].isNull || edges[e].sc != 0) ? 1 : 0;
     if (outOf[j].empty()) notPlain = 1;   // would leave an empty entry in an otherwise full plain row
-    type[j] = Type{(int)outOf[j].size(), hasS, notPlain};
+    int cls = 7;
+    for (int e : outOf[j]) cls = cls == 7 ? edges[e].sc : (cls == edges[e].sc ? cls : 4);
+    type[j] = Type{(int)outOf[j].size(), hasS, notPlain, cls};
     maxOut = std::max(maxOut, type[j][0]);
     nNullDest += hasS;
   }
@@ -114,7 +117,7 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
     std::vector<unsigned> admits(types.size(), 0), own(types.size(), 0);
     for (size_t t = 0; t < types.size(); ++t)
       for (int k = 0; k < K; ++k)
-        if (types[t][0] <= caps[k][0] && types[t][1] <= caps[k][1] && types[t][2] <= caps[k][2]) {
+        if (types[t][0] <= caps[k][0] && types[t][1] <= caps[k][1] && types[t][2] <= caps[k][2] && ((caps[k][3] >> types[t][3]) & 1)) {
           admits[t] |= 1u << k;
           if (types[t][1] == caps[k][1]) own[t] |= 1u << k;     // S rows are kept for the states that need them
         }
@@ -162,15 +165,21 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
     return true;
   };
   auto score = [&](const std::vector<int>& rows, int* readsOut, int* backOut, int* entriesOut) -> double {
-    std::vector<Type> shape(K, Type{0, 0, 0});
+    std::vector<Type> shape(K, Type{0, 0, 0, 0});
     for (int j = 0; j < N; ++j)
       for (int q = 0; q < 3; ++q) shape[rows[j]][q] = std::max(shape[rows[j]][q], type[j][q]);
     std::vector<char> inUse(K, 0);
     for (int j = 0; j < N; ++j) inUse[rows[j]] = 1;
     int reads = 0, entries = 0;
-    double offerCost = 0;   // an entry of a plain row is offered with a third of the instructions
+    double offerCost = 0;   // in units of one fully decoded entry
     for (int k = 0; k < K; ++k)
-      if (inUse[k]) { reads += 1 + shape[k][1]; entries += shape[k][0]; offerCost += shape[k][2] ? shape[k][0] : 0.4 * shape[k][0]; }
+      if (inUse[k]) {
+        int clsMask = 0;
+        for (int j = 0; j < N; ++j) if (rows[j] == k && type[j][3] != 7) clsMask |= 1 << type[j][3];
+        const bool oneClass = clsMask != 0 && (clsMask & (clsMask - 1)) == 0 && clsMask < 16;
+        reads += 1 + shape[k][1]; entries += shape[k][0];
+        offerCost += !shape[k][2] ? 0.25 * shape[k][0] : (oneClass ? 0.55 * shape[k][0] : shape[k][0]);
+      }
     std::vector<int> f(N, 0), g(N);
     for (int h = 0; h < kWalk; ++h) {
       std::fill(g.begin(), g.end(), 0);
@@ -183,8 +192,10 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
     int back = 0;
     for (int v : f) back = std::max(back, v);
     *readsOut = reads; *backOut = back; *entriesOut = entries;
-    // a sweep costs its accumulator reads plus, where cells grew, one offer per entry
-    return ((double)reads + offerCost + 10.0) * (double)(back + 1);
+    // A sweep costs its accumulator reads plus, where cells grew, one offer per entry (an offer is what
+    // most of a sweep's instructions go to; entries whose kind / class is a property of the row are far
+    // cheaper).  Sweeps: the GPU needs about 8 + back/2 (measured on s16h74l4c4 layouts with back 12..17).
+    return (0.5 * (double)reads + 1.5 * offerCost + 5.0) * (8.0 + 0.5 * (double)back);
   };
   auto ldsNeed = [&](int nS) { return (size_t)(p.NS + nS * T + 8 + 28 + T / 64 + (T / 64 + 2) / 2 + 1) * sizeof(double); };
 
@@ -211,7 +222,8 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
       if ((size_t)KU * T < (size_t)N) continue;
       for (int groups = 1; groups <= std::max(1, std::min(3, nS)); ++groups) {
         for (int ascending = 0; ascending < 2; ++ascending)
-        for (int plainRows = 0; plainRows < 2; ++plainRows) {
+        for (int plainRows = 0; plainRows < 2; ++plainRows)
+        for (int typedS = 0; typedS < 2; ++typedS) {
           // kinds: the S rows in `groups` runs spread evenly over the program
           std::vector<int> isS(K, 0);
           for (int g = 0, left = nS; g < groups && nS > 0; ++g) {
@@ -238,20 +250,36 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
               const size_t have = (size_t)(std::upper_bound(outPlainP.begin(), outPlainP.end(), cap) - outPlainP.begin());
               if (have >= (size_t)(nPlainRows + 1) * T) { generic = 0; ++nPlainRows; }
             }
-            caps[k] = k < KU ? Type{cap, isS[k], generic} : Type{-1, -1, -1};   // closed rows admit nothing
+            caps[k] = k < KU ? Type{cap, isS[k], generic, 0xff} : Type{-1, -1, -1, 0};   // closed rows admit nothing
             ++seen;
+          }
+          if (typedS && nS > 0) {
+            // S rows of one score class each (the kernel then adds the score without decoding it): rows are
+            // allotted to the classes by their share of the states with null in-edges, largest class first;
+            // what is left over stays open to every class
+            std::array<long, 8> cnt{};
+            for (int j = 0; j < N; ++j) if (type[j][1]) ++cnt[(size_t)type[j][3]];
+            std::vector<int> sRows;
+            for (int k = 0; k < KU; ++k) if (isS[k]) sRows.push_back(k);
+            std::vector<int> order{0, 1, 2, 3};
+            std::stable_sort(order.begin(), order.end(), [&](int a2, int b2) { return cnt[(size_t)a2] > cnt[(size_t)b2]; });
+            size_t next = 0;
+            for (int c : order) {
+              const long need = (cnt[(size_t)c] + T - 1) / T;
+              for (long r = 0; r < need && next < sRows.size(); ++r) caps[sRows[next++]][3] = (1 << c) | (1 << 7);
+            }
           }
           std::vector<int> rows;
           if (!deal(caps, &rows)) continue;
           int reads = 0, back = 0, entries = 0;
           const double sc = score(rows, &reads, &back, &entries);
           if (getenv("DNAS_PLAN_DEBUG"))
-            fprintf(stderr, "plan candidate: rows %d S-rows %d groups %d ascending %d plain %d -> reads %d entries %d back %d score %.0f\n", KU, nS,
-                    groups, ascending, plainRows, reads, entries, back, sc);
+            fprintf(stderr, "plan candidate: rows %d S-rows %d groups %d ascending %d plain %d typedS %d -> reads %d entries %d back %d score %.0f\n", KU, nS,
+                    groups, ascending, plainRows, typedS, reads, entries, back, sc);
           if (const char* pick = getenv("DNAS_PLAN_PICK")) {   // experiments: "rows,S-rows,groups,ascending"
-            int a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
-            if (sscanf(pick, "%d,%d,%d,%d,%d", &a0, &a1, &a2, &a3, &a4) == 5 &&
-                (a0 != KU || a1 != nS || a2 != groups || a3 != ascending || a4 != plainRows)) continue;
+            int a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
+            if (sscanf(pick, "%d,%d,%d,%d,%d,%d", &a0, &a1, &a2, &a3, &a4, &a5) == 6 &&
+                (a0 != KU || a1 != nS || a2 != groups || a3 != ascending || a4 != plainRows || a5 != typedS)) continue;
           }
           if (entries > kMaxEntries) { why = "row shapes need " + std::to_string(entries) + " entry registers per thread"; continue; }
           if (bestScore < 0 || sc < bestScore) {
@@ -296,7 +324,7 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
             for (int k2 = 0; k2 < K; ++k2) {
               if (k2 == k || fill[k2] >= T) continue;
               const Type& c2 = bestCaps[k2];
-              if (type[j][0] > c2[0] || type[j][1] > c2[1] || type[j][2] > c2[2]) continue;
+              if (type[j][0] > c2[0] || type[j][1] > c2[1] || type[j][2] > c2[2] || !((c2[3] >> type[j][3]) & 1)) continue;
               const int have = common(k2);
               const int mine = attr == 0 ? clsOf(j) : kindOf(j);
               if (!(have == (attr == 0 ? -1 : 0) || have == mine || have == -2)) continue;   // would spoil k2
