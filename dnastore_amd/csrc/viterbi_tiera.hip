@@ -112,6 +112,9 @@ __device__ __forceinline__ unsigned opaque(unsigned v) {
 constexpr double kNegInf = -__builtin_huge_val();
 constexpr double kFresh = __builtin_huge_val();   // "not evaluated in this column yet" in a D register
 
+#ifndef DNAS_SLEEP
+#define DNAS_SLEEP 1   // idle waves poll the termination words every 64 * DNAS_SLEEP cycles
+#endif
 #ifndef DNAS_NT_H
 #define DNAS_NT_H 1   // how many of the oldest history columns are streamed
 #endif
@@ -327,7 +330,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
           const unsigned v = ln < NW ? __hip_atomic_load(&idleL[ln], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : e0 + 1u;
           if (__all(v == e0 + 1u)) { done = true; break; }
           if (__hip_atomic_load(epochL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != e0) break;   // someone grew a cell: sweep again
-          __builtin_amdgcn_s_sleep(1);
+          __builtin_amdgcn_s_sleep(DNAS_SLEEP);
         }
         if (done) break;
       }
