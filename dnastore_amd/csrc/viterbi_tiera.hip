@@ -121,9 +121,6 @@ constexpr double kFresh = __builtin_huge_val();   // "not evaluated in this colu
 #ifndef DNAS_NT_D
 #define DNAS_NT_D 1
 #endif
-#ifndef DNAS_LOCKSTEP
-#define DNAS_LOCKSTEP 0
-#endif
 
 extern "C" __global__ void __launch_bounds__(DNAS_T)
 viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntries][T]
@@ -312,11 +309,6 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
             });
           }
         });
-#if DNAS_LOCKSTEP   // experiment: a barrier per sweep keeps the waves in step
-        ++rounds;
-        if (!__syncthreads_or(changed)) break;
-      }
-#else
         ++rounds;
         if (__any(changed)) {
           // the offers above precede the bump (LDS operations of one wave execute in order)
@@ -334,7 +326,6 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
         }
         if (done) break;
       }
-#endif
       __syncthreads();   // all waves are out of the sweeps before phase C clears the accumulators
     }
     STAMP(tB)
@@ -374,13 +365,9 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
             static_for<k0 / 2, k1 / 2>([&](auto mc) {
               constexpr int m2 = mc.value;
               if constexpr (!rowLive(2 * m2) && !rowLive(2 * m2 + 1)) return;
-#ifdef DNAS_DIAG_NO_HIST   // timing experiment
-              dbl2 v2; v2.x = S[2 * m2]; v2.y = S[2 * m2 + 1];
-#else
               const dbl2* const hp = reinterpret_cast<const dbl2*>(col - (size_t)i * lanes * NS + (size_t)m2 * 2 * T) + tid;
               // the oldest column is read for the last time: stream it past the caches
               const dbl2 v2 = (DNAS_NT_H && i >= D_ - DNAS_NT_H) ? __builtin_nontemporal_load(hp) : *hp;
-#endif
               sh[2 * m2 - k0][i - 1] = v2.x;
               sh[2 * m2 + 1 - k0][i - 1] = v2.y;
             });
