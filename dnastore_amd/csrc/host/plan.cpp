@@ -79,10 +79,12 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
   // (states with null in-edges) -- and the states are dealt onto it along a depth-first walk
   // of the machine, each state into the first row behind its parent's row whose shape admits
   // it: a chain runs down the rows of one sweep instead of along one row.  Candidate programs
-  // (how many S rows, in how many groups, uniform or ascending entry counts, last row left empty)
-  // are scored by (cost of a sweep: accumulator reads + entries) x (sweeps, estimated as the
+  // (how many S rows, in how many groups, uniform or ascending entry counts, rows reserved for
+  // "plain" states, S rows of one score class each, last row left empty) are scored by (cost of a
+  // sweep: accumulator reads + what the offers of its entries cost) x (sweeps, estimated from the
   // largest number of backward edges on any walk of kWalk edges); the best one that fits the
-  // registers and the LDS is kept.
+  // registers and the LDS is kept.  DNAS_PLAN_DEBUG=1 prints the candidates, DNAS_PLAN_PICK=
+  // "rows,S-rows,groups,ascending,plain,typedS" forces one (experiments).
   std::vector<int> pre(N, -1), parent(N, -1), walk;
   walk.reserve(N);
   {
