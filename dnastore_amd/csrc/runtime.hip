@@ -303,7 +303,7 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
   for (int64_t i = 0; i < n_reads; ++i) {
     const uint64_t L = read_offsets[order[i] + 1] - read_offsets[order[i]];
     if (L > 0x7ffffff0ull) return dnas::fail(DNAS_E_UNSUPPORTED, "read too long");
-    const size_t need = colDoubles * (size_t)(L + 1);
+    const size_t need = colDoubles * (size_t)(L + 1) + 8;   // + a spare cell (tier A, local mode: S(N-1, L) before its overwrite)
     if (need > arenaCapDoubles)
       return dnas::fail(DNAS_E_NOMEM, "a single read's lattice (" + std::to_string(need * 8) +
                                           " bytes) exceeds the lattice arena (" + std::to_string(m->arenaCap) + ")");

@@ -111,10 +111,25 @@ __device__ __forceinline__ double cell_at(const DevModel& m, const double* __res
 // out[(pos*(D+2)+lane)*N + state], whatever the storage tier.  grid = L+1, any block size.
 extern "C" __global__ void expand_lattice_kernel(DevModel m, const uint8_t* __restrict__ seq, const double* __restrict__ lat,
                                                  double* __restrict__ out) {
-  const int ps = blockIdx.x, lanes = m.D + 2;
+  const int ps = blockIdx.x, lanes = m.D + 2, L = (int)gridDim.x - 1;
   for (int st = threadIdx.x; st < m.N; st += blockDim.x)
-    for (int ln = 0; ln < lanes; ++ln)
-      out[((size_t)ps * lanes + ln) * m.N + st] = lattice_cell(m, lat, seq, st, ps, ln);
+    for (int ln = 0; ln < lanes; ++ln) {
+      double v = lattice_cell(m, lat, seq, st, ps, ln);
+      if (m.local && m.storedLanes == 2 && ln >= 2 && ps == L && st == m.N - 1 && L >= 1) {
+        // local mode: the reference formed T(N-1, L, .) from S(N-1, L) BEFORE overwriting that cell with the
+        // column maximum (viterbi.cpp:161-173); the fill kernel kept the earlier value behind the lattice
+        const int k = ln - 2, mdl = m.mdl[st];
+        if (k < mdl) {
+          const double s0 = lat[(size_t)(L + 1) * 2 * (size_t)m.Npad];
+          const double opened = (s0 + m.tanDup) + m.len[k];
+          // T(L,k) = max( T(L-1,k+1) + sub[ctx[k+1]][x_L],  opened ):  the first term does not involve S(L)
+          double shifted = kNegInf;
+          if (k + 1 < mdl) shifted = lattice_cell(m, lat, seq, st, ps - 1, ln + 1) + m.sub[m.ctx[(size_t)st * m.D + k + 1] * 4 + seq[ps - 1]];
+          v = dmax(shifted, opened);
+        }
+      }
+      out[((size_t)ps * lanes + ln) * m.N + st] = v;
+    }
 }
 
 // grid = reads in this batch, block = kFillThreads.

@@ -450,7 +450,13 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
   if (a.local) {
     static_for<0, K>([&](auto kc) {
       constexpr int k = kc.value;
-      if (META(k) & 0x40000000u) lastS[(k >> 1) * 2 * T + 2 * tid + (k & 1)] = red[0];
+      if (META(k) & 0x40000000u) {
+        // the reference overwrites S(N-1, L) AFTER the duplication lanes of the last column were formed
+        // from it (viterbi.cpp:161-173); those lanes are not stored here, so the value they came from is
+        // kept in the spare cell behind the read's lattice for whoever rebuilds them (expand_lattice_kernel)
+        lat[(size_t)(L + 1) * lanes * NS] = S[k];
+        lastS[(k >> 1) * 2 * T + 2 * tid + (k & 1)] = red[0];
+      }
     });
   }
 }

@@ -1,0 +1,30 @@
+"""Random machines (tests/random_machines.py) through the real HIP path: decoded strings, fp64
+log-likelihoods and every lattice cell bit-identical to the oracle, under both fill kernels."""
+import numpy as np
+import pytest
+
+from random_machines import random_machine, random_read
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed,n_states,global_", [(1, 40, True), (2, 90, False), (3, 150, True), (6, 2300, True), (7, 5000, False)])
+@pytest.mark.parametrize("tier", ["A", "B"])
+def test_random_machine_gpu_matches_oracle(oracle_mod, seed, n_states, global_, tier, monkeypatch):
+    import dnastore_amd as da
+    O = oracle_mod
+    if tier == "B":
+        monkeypatch.setenv("DNAS_TIER", "B")
+    text = random_machine(seed, n_states)
+    flags = dict(global_=global_, sub=.02, dup=.01, del_open=.02, del_ext=.1)
+    dec = da.ViterbiDecoder(da.Machine.fromJSON(text), da.MutatorParams.fromFlags(**flags))
+    assert dec.tier.startswith("tier " + tier)
+    orc = O.ViterbiOracle(O.Machine.from_json(text), O.MutatorParams.from_cli(**flags))
+    reads = [random_read(100 * seed + r, text, max_len=30) for r in range(4)]
+    out, ll, st = dec.decode(reads)
+    for i, r in enumerate(reads):
+        s, oll, olat = orc.decode(r, want_lattice=True)
+        assert out[i] == s and (ll[i] == oll or (np.isinf(ll[i]) and np.isinf(oll)))
+        lat = np.ascontiguousarray(dec.lattice(i, len(r)).transpose(0, 2, 1))
+        assert np.array_equal(lat.view(np.uint64), olat.view(np.uint64))
+    dec.close()
