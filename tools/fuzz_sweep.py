@@ -1,0 +1,44 @@
+"""Wider fuzz run than the test suite's: many random machines / error models / reads, GPU (tier A and B)
+against the oracle: decoded string, log-likelihood, status and every lattice cell.
+  python tools/fuzz_sweep.py 40"""
+import os, sys, random
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import dnastore_amd as da
+from oracle import oracle as O
+from random_machines import random_machine, random_read
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+BASE = int(sys.argv[2]) if len(sys.argv) > 2 else 9000
+bad = 0
+for case in range(n_cases):
+    rng = random.Random(BASE + case)
+    n_states = rng.choice([12, 40, 200, 700, 1500, 2300, 4200, 6500, 9000])
+    text = random_machine(BASE + 500 + case, n_states)
+    flags = dict(global_=rng.random() < 0.5, sub=rng.choice([0., .01, .05]), dup=rng.choice([0., .001, .02]),
+                 del_open=rng.choice([0., .001, .03]), del_ext=rng.choice([.01, .2]), length=rng.choice([4, 8, 12]))
+    orc = O.ViterbiOracle(O.Machine.from_json(text), O.MutatorParams.from_cli(**flags))
+    reads = [random_read(7000 + 10 * case + r, text, max_len=rng.choice([5, 25, 60]), noise=rng.choice([0., .1, .3])) for r in range(3)]
+    reads.append("")                       # an empty read in every batch
+    want = [orc.decode(r, want_lattice=True) for r in reads]
+    for tier in ("A", "B"):
+        if tier == "B":
+            os.environ["DNAS_TIER"] = "B"
+        else:
+            os.environ.pop("DNAS_TIER", None)
+        dec = da.ViterbiDecoder(da.Machine.fromJSON(text), da.MutatorParams.fromFlags(**flags))
+        out, ll, st = dec.decode(reads)
+        for i, r in enumerate(reads):
+            s, oll, olat = want[i]
+            ok = out[i] == s and (ll[i] == oll or (np.isinf(ll[i]) and np.isinf(oll)))
+            lat = np.ascontiguousarray(dec.lattice(i, len(r)).transpose(0, 2, 1))
+            nbad = int((lat.view(np.uint64) != olat.view(np.uint64)).sum())
+            if not ok or nbad:
+                bad += 1
+                print("MISMATCH case %d tier %s N=%d flags %s read %d %r: gpu %r %r st %d | oracle %r %r | cells %d" % (
+                    case, dec.tier[:6], n_states, flags, i, r, out[i], ll[i], st[i], s, oll, nbad), flush=True)
+        dec.close()
+    print("case %d N=%d %s ok" % (case, n_states, "global" if flags["global_"] else "local"), flush=True)
+print("%d cases, %d mismatches" % (n_cases, bad))
+sys.exit(1 if bad else 0)
