@@ -123,3 +123,34 @@ def test_bad_base_rejected(da, ref_data):
     with pytest.raises(ValueError):
         dec.decode(["ACGTN"])
     dec.close()
+
+
+def test_many_small_batches_equal_one_batch(da, ref_data, monkeypatch):
+    """Ping-pong arenas and batch scheduling: the same reads cut into many launches (3 slots each, and again
+    with an arena that holds only two lattices) give exactly the bits of a single launch."""
+    import random
+    path = os.path.join(ref_data, "h74l4c4.json")
+    m = da.Machine.fromFile(path)
+    params = da.MutatorParams.fromFlags()
+    rng = random.Random(5)
+    reads = [m.encodeBytes(bytes(rng.randrange(256) for _ in range(rng.choice([1, 3, 6])))) for _ in range(23)]
+    reads[4] = reads[4][:9]
+    reads[11] = ""
+    dec = da.ViterbiDecoder(m, params)
+    want = dec.decode(reads)
+    assert dec.stats()["fill_launches"] == 1
+    dec.close()
+    monkeypatch.setenv("DNAS_MAX_SLOTS", "3")
+    dec = da.ViterbiDecoder(m, params)
+    got = dec.decode(reads)
+    assert dec.stats()["fill_launches"] == 8
+    assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+    dec.close()
+    monkeypatch.delenv("DNAS_MAX_SLOTS")
+    longest = max(len(r) for r in reads)
+    n_pad = 6 * 1024                                            # tier A row stride of this machine (5 242 states)
+    dec = da.ViterbiDecoder(m, params, arena_bytes=2 * 2 * (2 * n_pad * (longest + 1) + 8) * 8 + 4096)
+    got = dec.decode(reads)
+    assert dec.stats()["fill_launches"] > 4
+    assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+    dec.close()
