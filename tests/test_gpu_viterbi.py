@@ -154,3 +154,32 @@ def test_many_small_batches_equal_one_batch(da, ref_data, monkeypatch):
     assert dec.stats()["fill_launches"] > 4
     assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
     dec.close()
+
+
+def test_device_pointer_entry_point_matches_host_entry_point(da, ref_data):
+    """dnas_viterbi_batch_device (inputs and outputs resident in HBM, what bench.py times) against
+    dnas_viterbi_batch (host buffers)."""
+    import random
+    import torch
+    m = da.Machine.fromFile(os.path.join(ref_data, "s16h74l4c4.json"))
+    dec = da.ViterbiDecoder(m, da.MutatorParams.fromFlags(global_=True))
+    rng = random.Random(21)
+    reads = [m.encodeBytes(bytes(rng.randrange(256) for _ in range(rng.choice([2, 5, 9])))) for _ in range(9)]
+    want_sym, want_ll, want_st = dec.decode(reads)
+    off, bases = da.pack_reads(reads)
+    dev = torch.device("cuda", 0)
+    d_bases = torch.from_numpy(np.ascontiguousarray(bases)).to(dev)
+    k = len(reads)
+    cap = int(np.diff(off).max()) + 64
+    out_off = np.arange(k + 1, dtype=np.uint64) * np.uint64(cap)
+    d_sym = torch.zeros(k * cap, dtype=torch.uint8, device=dev)
+    d_len = torch.zeros(k, dtype=torch.int32, device=dev)
+    d_ll = torch.zeros(k, dtype=torch.float64, device=dev)
+    d_st = torch.zeros(k, dtype=torch.uint8, device=dev)
+    dec.decode_device(off, d_bases.data_ptr(), d_sym.data_ptr(), out_off, d_len.data_ptr(), d_ll.data_ptr(), d_st.data_ptr())
+    dec.sync()
+    sym, olen = d_sym.cpu().numpy(), d_len.cpu().numpy()
+    got = [sym[i * cap:i * cap + int(olen[i])].tobytes().decode() for i in range(k)]
+    assert got == want_sym
+    assert np.array_equal(d_ll.cpu().numpy(), want_ll) and np.array_equal(d_st.cpu().numpy(), want_st)
+    dec.close()
