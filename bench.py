@@ -110,6 +110,10 @@ def main():
     k = len(off) - 1
     lens = np.diff(off).astype(np.int64)
     cap = int(lens.max()) + 64 if k else 64
+    if world > 1:   # the gathered symbol buffers must have one shape on every rank
+        tcap = torch.tensor([cap], dtype=torch.int64, device=device)
+        dist.all_reduce(tcap, op=dist.ReduceOp.MAX)
+        cap = int(tcap.item())
     out_off = (np.arange(k + 1, dtype=np.uint64) * np.uint64(cap))
     d_sym = torch.zeros(max(k * cap, 1), dtype=torch.uint8, device=device)
     d_len = torch.zeros(max(k, 1), dtype=torch.int32, device=device)

@@ -64,6 +64,11 @@ def gather_results(sym, out_len, loglike, status, world, rank):
     on rank 0 a list over ranks of the same tuples (None elsewhere).  Equal k on every rank."""
     if not _dist_ready(world):
         return [(sym, out_len, loglike, status)]
+    # a gather of unequal shapes would hang or corrupt: check once, loudly
+    shape = torch.tensor([sym.numel(), -sym.numel(), out_len.numel(), -out_len.numel()], dtype=torch.int64, device=sym.device)
+    dist.all_reduce(shape, op=dist.ReduceOp.MAX)
+    if int(shape[0]) != -int(shape[1]) or int(shape[2]) != -int(shape[3]):
+        raise ValueError("gather_results: result buffers differ in size across ranks (use one output capacity and read count)")
     outs = []
     for t in (sym, out_len, loglike, status):
         bucket = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
