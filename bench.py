@@ -88,11 +88,20 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    # DNAS_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks (the ranks
+    # share the cards, the collectives run on host copies); the measured configuration is always nccl (= RCCL)
+    backend = os.environ.get("DNAS_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    coll_device = device if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     machine = da.Machine.fromFile(MACHINE)
     params = da.MutatorParams.fromFlags(global_=True)
@@ -106,12 +115,13 @@ def main():
         off_all, bases_all = da.pack_reads(all_reads)
     else:
         off_all, bases_all = None, None
-    idx, off, d_bases = shard.scatter_reads(off_all, bases_all, world, rank, device)
+    idx, off, d_bases = shard.scatter_reads(off_all, bases_all, world, rank, coll_device)
+    d_bases = d_bases.to(device)
     k = len(off) - 1
     lens = np.diff(off).astype(np.int64)
     cap = int(lens.max()) + 64 if k else 64
     if world > 1:   # the gathered symbol buffers must have one shape on every rank
-        tcap = torch.tensor([cap], dtype=torch.int64, device=device)
+        tcap = torch.tensor([cap], dtype=torch.int64, device=coll_device)
         dist.all_reduce(tcap, op=dist.ReduceOp.MAX)
         cap = int(tcap.item())
     out_off = (np.arange(k + 1, dtype=np.uint64) * np.uint64(cap))
@@ -125,7 +135,7 @@ def main():
         dec.decode_device(off, d_bases.data_ptr(), d_sym.data_ptr(), out_off, d_len.data_ptr(), d_ll.data_ptr(),
                           d_st.data_ptr())
         dec.sync()
-        return shard.gather_results(d_sym, d_len, d_ll, d_st, world, rank)
+        return shard.gather_results(d_sym.to(coll_device), d_len.to(coll_device), d_ll.to(coll_device), d_st.to(coll_device), world, rank)
 
     def fence():
         torch.cuda.synchronize()
@@ -148,7 +158,7 @@ def main():
         tb_ms += stats["traceback_ms"]
     fence()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed, float(shard_nt)], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed, float(shard_nt)], dtype=torch.float64, device=coll_device)
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
