@@ -25,3 +25,19 @@ def oracle_mod():
     from oracle import oracle as O
     O.build()
     return O
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_cuda_first():
+    """The PyTorch ROCm wheel bundles its own HIP runtime (torch/lib/libamdhip64.so) while libdnastore_amd.so links
+    the system one (/opt/rocm/lib/libamdhip64.so.7): a process that uses both ends up with two runtimes.  That works
+    when PyTorch's comes up first (the order bench.py uses); bringing it up after the library has already created and
+    destroyed device state can fail with "No HIP GPUs are available".  So on a GPU box the test session initialises
+    torch.cuda before anything else; without a GPU this is a no-op."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+    yield
