@@ -117,6 +117,7 @@ def main():
         off_all, bases_all = None, None
     idx, off, d_bases = shard.scatter_reads(off_all, bases_all, world, rank, coll_device)
     d_bases = d_bases.to(device)
+    torch.cuda.synchronize()   # the library launches on its own streams: the scattered reads must have landed
     k = len(off) - 1
     lens = np.diff(off).astype(np.int64)
     cap = int(lens.max()) + 64 if k else 64
