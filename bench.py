@@ -144,6 +144,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    torch.cuda.synchronize()   # torch's fills of the output buffers are done before the library's streams write them
     for _ in range(args.warmup):
         step()
     fence()
