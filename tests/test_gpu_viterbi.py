@@ -176,6 +176,7 @@ def test_device_pointer_entry_point_matches_host_entry_point(da, ref_data):
     d_len = torch.zeros(k, dtype=torch.int32, device=dev)
     d_ll = torch.zeros(k, dtype=torch.float64, device=dev)
     d_st = torch.zeros(k, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()    # torch's copies / fills are done before the library's own streams touch the buffers
     dec.decode_device(off, d_bases.data_ptr(), d_sym.data_ptr(), out_off, d_len.data_ptr(), d_ll.data_ptr(), d_st.data_ptr())
     dec.sync()
     sym, olen = d_sym.cpu().numpy(), d_len.cpu().numpy()
