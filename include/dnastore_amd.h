@@ -144,7 +144,9 @@ int dnas_viterbi_batch(dnas_model *model, int64_t n_reads, const uint64_t *read_
 
 /* Same, with bases and all outputs already resident in this GPU's HBM (device pointers);
  * read_offsets / out_offsets stay host arrays (they drive batching).  Asynchronous on the
- * model's stream; dnas_model_sync waits. */
+ * model's own streams; dnas_model_sync waits.  The library does not know the caller's streams:
+ * whatever produced d_bases (and any fill of the output buffers) must have completed before the
+ * call, and the outputs may be read after dnas_model_sync. */
 int dnas_viterbi_batch_device(dnas_model *model, int64_t n_reads, const uint64_t *read_offsets,
                               const uint8_t *d_bases, char *d_out_sym, const uint64_t *out_offsets,
                               uint32_t *d_out_len, double *d_out_loglike, uint8_t *d_out_status);
