@@ -216,13 +216,19 @@ extern "C" int dnas_model_create(const dnas_flat_model* fm, int device_id, size_
   if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return bail(dnas::fail(DNAS_E_DEVICE, "hipMemGetInfo failed"));
   m->arenaCap = arena_bytes ? arena_bytes : (size_t)((double)freeB * 0.6);
   if (m->tier == 1) {
-    // A tier-A work-group owns a whole CU (all of its vector registers and nearly all of its LDS),
-    // so a launch runs in rounds of one read per CU.  The traceback of the previous batch runs
-    // beside the fill on one CU (a single block): a launch of two rounds over the REMAINING CUs
-    // ends with them, while one work-group more would wait for a third round.
+    // A tier-A work-group owns a whole CU (all of its vector registers and nearly all of its LDS), so
+    // a launch runs in rounds of one read per CU -- per XCD: work-groups are dealt round-robin to the
+    // XCDs (32 CUs each), and an XCD that gets one work-group more than rounds x its free CUs adds a
+    // whole round to the launch.  The traceback of the previous batch runs beside the fill (blocks of
+    // 512 reads, one CU each), and a round with a few CUs of an XCD idle is faster than a full one
+    // (the XCD's 4 MB L2 holds the S history of ~17 work-groups).  Measured on MI355X with the bench
+    // workload: three rounds of 30 work-groups per XCD (720 reads) per launch, 48.8 ms, is the best
+    // point; 2 x 255 = 510 reads cost 48 ms (a third round on the traceback's XCD), 500 reads 37 ms.
     int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 1)
-      m->maxSlots = std::max(1, 2 * (cus - 1));
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 1) {
+      const int xcds = std::max(1, cus / 32);
+      m->maxSlots = std::max(1, 3 * (cus - 2 * xcds));
+    }
   }
   if (const char* s = getenv("DNAS_MAX_SLOTS")) m->maxSlots = std::max(1, atoi(s));
   *out = m;

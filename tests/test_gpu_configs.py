@@ -103,7 +103,7 @@ def test_config3_roundtrip_at_scale(da, ref_data):
     import bench
     m = da.Machine.fromFile(bench.MACHINE)
     dec = da.ViterbiDecoder(m, da.MutatorParams.fromFlags(global_=True))
-    n = 600                                                     # more than one batch of 512
+    n = 800                                                     # more than one launch (720 reads per launch on MI355X)
     reads = bench.make_reads(m, 0, n)
     out, ll, st = dec.decode(reads)
     assert not st.any() and np.isfinite(ll).all()
