@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=10000, help="reads per GPU (config 3: 10k)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline time budget (0 = skip)")
+    ap.add_argument("--arena-gb", type=float, default=0.0, help="lattice arena per GPU (0 = the library's default, 60 %% of free HBM)")
     args = ap.parse_args()
 
     import torch
@@ -105,7 +106,7 @@ def main():
 
     machine = da.Machine.fromFile(MACHINE)
     params = da.MutatorParams.fromFlags(global_=True)
-    dec = da.ViterbiDecoder(machine, params, device=local_rank)
+    dec = da.ViterbiDecoder(machine, params, device=local_rank, arena_bytes=int(args.arena_gb * 1e9))
 
     # ---- inputs: rank 0 makes the whole job's reads and scatters them (RCCL), untimed
     total_reads = args.reads * world
