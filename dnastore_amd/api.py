@@ -165,6 +165,30 @@ class FlatModel:
                                                  ctypes.addressof(ne), ctypes.addressof(ns)))
         return shapes, ent, meta, ns.value
 
+    def cluster_plan(self, members=0):
+        """Tier-C tables (members = 1: the tier-A plan): dict(G, K, T, n_entries, n_s_rows, n_g_rows, shapes int32[K][7],
+        entries uint32[G][n_entries][T], meta uint32[G][K][T], member_of, lds_index, lattice_slot)."""
+        n = self.view.contents.n_states
+        info = np.zeros(8, dtype=np.int32)
+        _l.check(_l.lib().dnas_tierc_plan(self.view, int(members), info.ctypes.data, None, None, 0, None, None, None, None))
+        G, K, T, ne = (int(v) for v in info[:4])
+        shapes = np.zeros((K, 7), dtype=np.int32)
+        ent = np.zeros((G, ne, T), dtype=np.uint32)
+        meta = np.zeros((G, K, T), dtype=np.uint32)
+        member_of = np.full(n, -1, dtype=np.int32)
+        lds = np.full(n, -1, dtype=np.int32)
+        lat = np.full(n, -1, dtype=np.int32)
+        _l.check(_l.lib().dnas_tierc_plan(self.view, G, info.ctypes.data, shapes.ctypes.data, ent.ctypes.data, ent.size, meta.ctypes.data,
+                                          member_of.ctypes.data, lds.ctypes.data, lat.ctypes.data))
+        return dict(G=G, K=K, T=T, n_entries=ne, n_s_rows=int(info[4]), n_g_rows=int(info[5]), shapes=shapes, entries=ent, meta=meta,
+                    member_of=member_of, lds_index=lds, lattice_slot=lat)
+
+    def precompile_cluster(self, members=0):
+        """JIT-specialise the cluster (tier C) fill kernel for this machine into the kernel cache (no GPU needed)."""
+        buf = ctypes.create_string_buffer(4096)
+        _l.check(_l.lib().dnas_tierc_precompile(self.view, int(members), buf, 4096))
+        return buf.value.decode()
+
     def precompile(self):
         """JIT-specialise the tier-A fill kernel for this machine into dnastore_amd/kcache (no GPU needed)."""
         buf = ctypes.create_string_buffer(1024)
@@ -190,12 +214,14 @@ def pack_reads(reads):
 class ViterbiDecoder:
     """A (machine, params) pair resident on one GPU; decode() is the batched ViterbiMatrix + traceback."""
 
-    def __init__(self, machine, params, device=0, arena_bytes=0):
+    def __init__(self, machine, params, device=0, arena_bytes=0, options=None):
+        """options: dnas_model_create_ex's "key=value,..." string, e.g. "tier=C,cluster=2"."""
         self.flat = FlatModel(machine, params)
         v = self.flat.view.contents
         self.n_states, self.max_dup_len = v.n_states, v.max_dup_len
         self._h = ctypes.c_void_p()
-        _l.check(_l.lib().dnas_model_create(self.flat.view, int(device), int(arena_bytes), ctypes.byref(self._h)))
+        _l.check(_l.lib().dnas_model_create_ex(self.flat.view, int(device), int(arena_bytes),
+                                               options.encode() if options else None, ctypes.byref(self._h)))
 
     def decode(self, reads, out_cap=None):
         """reads: list of str (ACGT, any case) -> (decoded symbol strings, loglike float64[n], status uint8[n])."""
@@ -228,6 +254,12 @@ class ViterbiDecoder:
     def tier(self):
         """'tier A: <shape>' or 'tier B: <reason>' -- which fill kernel serves this machine."""
         return _l.lib().dnas_model_tier(self._h).decode()
+
+    def cluster_census(self):
+        """Tier C, last call: (clusters that ran, clusters whose members sat on more than one XCD)."""
+        c, s = ctypes.c_int32(), ctypes.c_int32()
+        _l.check(_l.lib().dnas_model_cluster_census(self._h, ctypes.addressof(c), ctypes.addressof(s)))
+        return c.value, s.value
 
     def stats(self):
         s = _l.BatchStatsC()

@@ -16,22 +16,63 @@ constexpr int kMaxEntries = 40;   // entry registers per thread the kernel can a
 constexpr int kWalk = 30;         // length of the walks the sweep estimate looks at
 
 struct Edge { int src, dst, sc, base, isNull; };
-typedef std::array<int, 4> Type;  // out-edges, has null in-edges, not plain (some out-edge is a null edge or carries a score),
-                                  // score class of the out-edges (4: they differ, 7: no out-edge) -- in a row's caps: the mask of classes it admits
+// out-edges, has null in-edges (and keeps its accumulators in LDS), not plain (some out-edge is a null edge or carries a
+// score), score class of the out-edges (4: they differ, 7: no out-edge) -- in a row's caps: the mask of classes it
+// admits --, has an in-edge from another member of the cluster (its accumulators live in the exchange buffer)
+typedef std::array<int, 5> Type;
 
-}  // namespace
+// Which member of the cluster owns which state.  The in-column recursion runs along the machine's chains, and every
+// edge between two members costs a trip through the exchange buffer (microseconds, against nanoseconds inside a CU):
+// the states are cut into G runs of the depth-first walk (a run is a set of subtrees: the composites here are long
+// chains with a branch every few states, so few edges leave a run), then single states move to the member most of
+// their neighbours are in while that lowers the cut and the member has room.
+std::vector<int> partitionStates(int N, const std::vector<Edge>& edges, const std::vector<int>& walk, int G, int cap) {
+  std::vector<int> part((size_t)N, 0);
+  for (int i = 0; i < N; ++i) part[(size_t)walk[(size_t)i]] = (int)((long)i * G / N);
+  std::vector<int> size((size_t)G, 0);
+  for (int j = 0; j < N; ++j) ++size[(size_t)part[(size_t)j]];
+  std::vector<std::vector<int>> nb((size_t)N);
+  for (const Edge& e : edges)
+    if (e.src != e.dst) { nb[(size_t)e.src].push_back(e.dst); nb[(size_t)e.dst].push_back(e.src); }
+  std::vector<int> cnt((size_t)G);
+  for (int pass = 0; pass < 4; ++pass) {
+    int moved = 0;
+    for (int i = 0; i < N; ++i) {
+      const int j = walk[(size_t)i];
+      if (nb[(size_t)j].empty()) continue;
+      std::fill(cnt.begin(), cnt.end(), 0);
+      for (int v : nb[(size_t)j]) ++cnt[(size_t)part[(size_t)v]];
+      const int cur = part[(size_t)j];
+      int best = cur;
+      for (int g = 0; g < G; ++g)
+        if (g != cur && size[(size_t)g] < cap && cnt[(size_t)g] > cnt[(size_t)best]) best = g;
+      if (best != cur) { part[(size_t)j] = best; --size[(size_t)cur]; ++size[(size_t)best]; ++moved; }
+    }
+    if (moved < N / 2000 + 1) break;
+  }
+  return part;
+}
 
-TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
+TierAPlan buildPlan(const dnas_flat_model& fm, const int G) {
   TierAPlan p;
   const int N = fm.n_states, D = fm.max_dup_len, T = kTierAThreads;
-  p.N = N; p.D = D; p.T = T;
+  p.N = N; p.D = D; p.T = T; p.G = G;
   auto no = [&](const std::string& why) { p.ok = false; p.whyNot = why; return p; };
   if (D > 8) return no("more than 8 duplication lanes");
+  if (G < 1 || G > kTierCMaxMembers) return no("cluster size out of range");
   // rows come in pairs: a thread's rows 2m and 2m+1 are neighbours in the HBM lattice, so that
   // the column goes out (and the S history comes back) as 16-byte accesses
-  const int K = 2 * ((N + 2 * T - 1) / (2 * T));
-  if (K > kTierAMaxRows) return no("more than " + std::to_string(kTierAMaxRows * T) + " states");
-  p.K = K; p.NS = K * T;
+  int K;
+  if (G == 1) {
+    K = 2 * ((N + 2 * T - 1) / (2 * T));
+  } else {
+    // a member's rows are dealt by shape (S rows, G rows, entry counts): leave them some air
+    const long perMember = (N + G - 1) / G;
+    K = 2 * (int)((perMember * 100 / 86 + 2 * T - 1) / (2 * T));
+    K = std::max(K, 2);
+  }
+  if (K > kTierAMaxRows) return no("more than " + std::to_string((long)kTierAMaxRows * T * G * (G == 1 ? 100 : 86) / 100) + " states");
+  p.K = K; p.NSm = K * T; p.NS = G * K * T;
 
   // score classes: 0.0 plus up to three distinct input-symbol log-probabilities
   std::vector<double> scores{0.0};
@@ -54,37 +95,8 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
 
   std::vector<std::vector<int>> outOf(N), inOf(N);   // edge indices
   for (size_t e = 0; e < edges.size(); ++e) { outOf[edges[e].src].push_back((int)e); inOf[edges[e].dst].push_back((int)e); }
-  std::vector<Type> type(N);
-  int maxOut = 0, nNullDest = 0;
-  for (int j = 0; j < N; ++j) {
-    int hasS = 0;
-    for (int e : inOf[j]) hasS |= edges[e].isNull;
-    int notPlain = 0;
-    for (int e : outOf[j]) notPlain |= (edges[e].isNull || edges[e].sc != 0) ? 1 : 0;
-    if (outOf[j].empty()) notPlain = 1;   // would leave an empty entry in an otherwise full plain row
-    int cls = 7;
-    for (int e : outOf[j]) cls = cls == 7 ? edges[e].sc : (cls == edges[e].sc ? cls : 4);
-    type[j] = Type{(int)outOf[j].size(), hasS, notPlain, cls};
-    maxOut = std::max(maxOut, type[j][0]);
-    nNullDest += hasS;
-  }
 
-  // ---- which state goes to which row ------------------------------------------------------
-  // A thread walks its rows 0..K-1 in every sweep, so a value crosses an edge within the same
-  // sweep when the destination sits in a LATER row than the source and needs another sweep
-  // otherwise.  The in-column recursion runs along the machine's chains (deletions follow the
-  // emit edges), so the number of sweeps to the fixpoint is about (how far a value travels) x
-  // (share of backward edges on its way).  The rows therefore form a "program" of shapes --
-  // how many out-edge entries a row's states may have, and whether the row carries S cells
-  // (states with null in-edges) -- and the states are dealt onto it along a depth-first walk
-  // of the machine, each state into the first row behind its parent's row whose shape admits
-  // it: a chain runs down the rows of one sweep instead of along one row.  Candidate programs
-  // (how many S rows, in how many groups, uniform or ascending entry counts, rows reserved for
-  // "plain" states, S rows of one score class each, last row left empty) are scored by (cost of a
-  // sweep: accumulator reads + what the offers of its entries cost) x (sweeps, estimated from the
-  // largest number of backward edges on any walk of kWalk edges); the best one that fits the
-  // registers and the LDS is kept.  DNAS_PLAN_DEBUG=1 prints the candidates, DNAS_PLAN_PICK=
-  // "rows,S-rows,groups,ascending,plain,typedS" forces one (experiments).
+  // depth-first walk of the machine (the partition and the row dealing both follow it)
   std::vector<int> pre(N, -1), parent(N, -1), walk;
   walk.reserve(N);
   {
@@ -106,6 +118,74 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
       }
     }
   }
+
+  // ---- which member of the cluster owns which state; which states are fed through the exchange buffer
+  std::vector<int> part(N, 0);
+  if (G > 1) part = partitionStates(N, edges, walk, G, (int)((long)K * T * 93 / 100));
+  std::vector<char> isG(N, 0);
+  long nCross = 0;
+  for (const Edge& e : edges)
+    if (part[e.src] != part[e.dst]) isG[e.dst] = 1;
+  for (const Edge& e : edges) nCross += isG[e.dst];
+  p.crossEdges = edges.empty() ? 0. : (double)nCross / (double)edges.size();
+  for (int j = 0; j < N; ++j)
+    if (parent[j] >= 0 && part[parent[j]] != part[j]) parent[j] = -1;   // the dealing follows a member's own subtrees
+  std::vector<std::vector<int>> walkOf(G);
+  for (int j : walk) walkOf[part[j]].push_back(j);
+  int nGRows = 0;
+  if (G > 1) {
+    std::vector<int> gCount(G, 0);
+    for (int j = 0; j < N; ++j) gCount[part[j]] += isG[j];
+    for (int g = 0; g < G; ++g) nGRows = std::max(nGRows, (gCount[g] + T - 1) / T);
+    if (nGRows == 0) nGRows = 1;   // (a cluster whose members never talk: keep the kernel's shape)
+  }
+  p.nGRows = nGRows;
+  if ((long)G * nGRows * T > (1l << 20)) return no("more than 2^20 exchange cells");
+
+  std::vector<Type> type(N);
+  int maxOut = 0, maxOutG = 0;
+  std::vector<int> nNullDestOf(G, 0);
+  for (int j = 0; j < N; ++j) {
+    int hasS = 0;
+    for (int e : inOf[j]) hasS |= edges[e].isNull;
+    if (isG[j]) hasS = 0;                 // a G row always carries an S cell (in the exchange buffer)
+    int notPlain = 0;
+    for (int e : outOf[j]) notPlain |= (edges[e].isNull || edges[e].sc != 0) ? 1 : 0;
+    if (outOf[j].empty()) notPlain = 1;   // would leave an empty entry in an otherwise full plain row
+    int cls = 7;
+    for (int e : outOf[j]) cls = cls == 7 ? edges[e].sc : (cls == edges[e].sc ? cls : 4);
+    type[j] = Type{(int)outOf[j].size(), hasS, notPlain, cls, (int)isG[j]};
+    (isG[j] ? maxOutG : maxOut) = std::max(isG[j] ? maxOutG : maxOut, type[j][0]);
+    nNullDestOf[part[j]] += hasS;
+  }
+  int nNullDestMax = 0;
+  for (int g = 0; g < G; ++g) nNullDestMax = std::max(nNullDestMax, nNullDestOf[g]);
+  if (getenv("DNAS_PLAN_DEBUG") && G > 1) {
+    std::vector<int> gc(G, 0);
+    for (int j = 0; j < N; ++j) gc[part[j]] += isG[j];
+    for (int g = 0; g < G; ++g)
+      fprintf(stderr, "plan member %d: %zu states, %d fed through the exchange buffer, %d with null in-edges in LDS\n", g, walkOf[g].size(), gc[g], nNullDestOf[g]);
+    fprintf(stderr, "plan: K %d exchange rows %d cross edges %.4f\n", K, nGRows, p.crossEdges);
+  }
+
+  // ---- which state goes to which row ------------------------------------------------------
+  // A thread walks its rows 0..K-1 in every sweep, so a value crosses an edge within the same
+  // sweep when the destination sits in a LATER row than the source and needs another sweep
+  // otherwise.  The in-column recursion runs along the machine's chains (deletions follow the
+  // emit edges), so the number of sweeps to the fixpoint is about (how far a value travels) x
+  // (share of backward edges on its way).  The rows therefore form a "program" of shapes --
+  // how many out-edge entries a row's states may have, and whether the row carries S cells
+  // (states with null in-edges) -- and the states are dealt onto it along a depth-first walk
+  // of the machine, each state into the first row behind its parent's row whose shape admits
+  // it: a chain runs down the rows of one sweep instead of along one row.  Candidate programs
+  // (how many S rows, in how many groups, uniform or ascending entry counts, rows reserved for
+  // "plain" states, S rows of one score class each, last row left empty) are scored by (cost of a
+  // sweep: accumulator reads + what the offers of its entries cost) x (sweeps, estimated from the
+  // largest number of backward edges on any walk of kWalk edges); the best one that fits the
+  // registers and the LDS is kept.  DNAS_PLAN_DEBUG=1 prints the candidates, DNAS_PLAN_PICK=
+  // "rows,S-rows,groups,ascending,plain,typedS" forces one (experiments).
+  // In a cluster the G rows come first: what another member offered is read at the start of a
+  // sweep and runs down the member's own rows within that sweep.  All members share the program.
   std::map<Type, int> typeId;
   std::vector<int> typeOf(N);
   std::vector<Type> types;
@@ -114,60 +194,65 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
     if (it == typeId.end()) { it = typeId.emplace(type[j], (int)types.size()).first; types.push_back(type[j]); }
     typeOf[j] = it->second;
   }
-  // deal the states onto a program (caps per row) along the depth-first walk
+  // deal the states of every member onto a program (caps per row) along the depth-first walk
   auto deal = [&](const std::vector<Type>& caps, std::vector<int>* rows) -> bool {
     std::vector<unsigned> admits(types.size(), 0), own(types.size(), 0);
     for (size_t t = 0; t < types.size(); ++t)
       for (int k = 0; k < K; ++k)
-        if (types[t][0] <= caps[k][0] && types[t][1] <= caps[k][1] && types[t][2] <= caps[k][2] && ((caps[k][3] >> types[t][3]) & 1)) {
+        if (types[t][0] <= caps[k][0] && types[t][1] <= caps[k][1] && types[t][2] <= caps[k][2] && ((caps[k][3] >> types[t][3]) & 1) &&
+            types[t][4] <= caps[k][4]) {
+          // (a state without an in-edge from another member may sit in an exchange row when nothing else is free: all its
+          //  in-edges then go through the exchange buffer)
           admits[t] |= 1u << k;
-          if (types[t][1] == caps[k][1]) own[t] |= 1u << k;     // S rows are kept for the states that need them
+          if (types[t][4] == caps[k][4] && (types[t][1] == caps[k][1] || caps[k][4])) own[t] |= 1u << k;     // S rows and exchange rows are kept for the states that need them
         }
-    std::vector<std::vector<int>> members(K);
-    unsigned freeRows = (1u << K) - 1u;
     rows->assign(N, -1);
-    auto put = [&](int j, int k) {
-      (*rows)[j] = k;
-      members[k].push_back(j);
-      if ((int)members[k].size() == T) freeRows &= ~(1u << k);
-    };
-    auto pick = [&](int j) -> int {
-      unsigned avail = own[typeOf[j]] & freeRows;
-      if (!avail) avail = admits[typeOf[j]] & freeRows;
-      if (!avail) return -1;
-      const int par = parent[j];
-      const int start = (par >= 0 && (*rows)[par] >= 0) ? (*rows)[par] + 1 : 0;
-      const unsigned fw = start < 32 ? avail & ~((1u << start) - 1u) : 0u;
-      return __builtin_ctz(fw ? fw : avail);
-    };
-    for (int j : walk) {
-      int k = pick(j);
-      if (k < 0) {
-        // every row that admits j is full: move a more flexible resident of one of them elsewhere
-        bool moved = false;
-        for (int r = 0; r < K && !moved; ++r) {
-          if (!(admits[typeOf[j]] >> r & 1u)) continue;
-          for (size_t m = 0; m < members[r].size(); ++m) {
-            const int i = members[r][m];
-            if (!(admits[typeOf[i]] & freeRows)) continue;
-            members[r].erase(members[r].begin() + (long)m);
-            freeRows |= 1u << r;
-            (*rows)[i] = -1;
-            put(i, pick(i));
-            moved = true;
-            break;
+    for (int g = 0; g < G; ++g) {
+      std::vector<std::vector<int>> members(K);
+      unsigned freeRows = (1u << K) - 1u;
+      auto put = [&](int j, int k) {
+        (*rows)[j] = k;
+        members[k].push_back(j);
+        if ((int)members[k].size() == T) freeRows &= ~(1u << k);
+      };
+      auto pick = [&](int j, unsigned exclude) -> int {
+        unsigned avail = own[typeOf[j]] & freeRows & ~exclude;
+        if (!avail) avail = admits[typeOf[j]] & freeRows & ~exclude;
+        if (!avail) return -1;
+        const int par = parent[j];
+        const int start = (par >= 0 && (*rows)[par] >= 0) ? (*rows)[par] + 1 : 0;
+        const unsigned fw = start < 32 ? avail & ~((1u << start) - 1u) : 0u;
+        return __builtin_ctz(fw ? fw : avail);
+      };
+      for (int j : walkOf[g]) {
+        int k = pick(j, 0u);
+        if (k < 0) {
+          // every row that admits j is full: move a more flexible resident of one of them elsewhere
+          bool moved = false;
+          for (int r = 0; r < K && !moved; ++r) {
+            if (!(admits[typeOf[j]] >> r & 1u)) continue;
+            for (size_t m = 0; m < members[r].size(); ++m) {
+              const int i = members[r][m];
+              if (!(admits[typeOf[i]] & freeRows & ~(1u << r))) continue;
+              members[r].erase(members[r].begin() + (long)m);
+              freeRows |= 1u << r;
+              (*rows)[i] = -1;
+              put(i, pick(i, 1u << r));
+              moved = true;
+              break;
+            }
           }
+          if (!moved) return false;
+          k = pick(j, 0u);
+          if (k < 0) return false;
         }
-        if (!moved) return false;
-        k = pick(j);
-        if (k < 0) return false;
+        put(j, k);
       }
-      put(j, k);
     }
     return true;
   };
   auto score = [&](const std::vector<int>& rows, int* readsOut, int* backOut, int* entriesOut) -> double {
-    std::vector<Type> shape(K, Type{0, 0, 0, 0});
+    std::vector<Type> shape(K, Type{0, 0, 0, 0, 0});
     for (int j = 0; j < N; ++j)
       for (int q = 0; q < 3; ++q) shape[rows[j]][q] = std::max(shape[rows[j]][q], type[j][q]);
     std::vector<char> inUse(K, 0);
@@ -179,14 +264,14 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
         int clsMask = 0;
         for (int j = 0; j < N; ++j) if (rows[j] == k && type[j][3] != 7) clsMask |= 1 << type[j][3];
         const bool oneClass = clsMask != 0 && (clsMask & (clsMask - 1)) == 0 && clsMask < 16;
-        reads += 1 + shape[k][1]; entries += shape[k][0];
+        reads += 1 + (k < nGRows ? 1 : shape[k][1]); entries += shape[k][0];
         offerCost += !shape[k][2] ? 0.25 * shape[k][0] : (oneClass ? 0.55 * shape[k][0] : shape[k][0]);
       }
     std::vector<int> f(N, 0), g(N);
     for (int h = 0; h < kWalk; ++h) {
       std::fill(g.begin(), g.end(), 0);
       for (const Edge& e : edges) {
-        const int v = f[e.src] + (rows[e.dst] <= rows[e.src] ? 1 : 0);
+        const int v = f[e.src] + ((rows[e.dst] <= rows[e.src] || part[e.dst] != part[e.src]) ? 1 : 0);
         if (v > g[e.dst]) g[e.dst] = v;
       }
       f.swap(g);
@@ -199,29 +284,49 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
     // cheaper).  Sweeps: the GPU needs about 8 + back/2 (measured on s16h74l4c4 layouts with back 12..17).
     return (0.5 * (double)reads + 1.5 * offerCost + 5.0) * (8.0 + 0.5 * (double)back);
   };
-  auto ldsNeed = [&](int nS) { return (size_t)(p.NS + nS * T + 8 + 28 + T / 64 + (T / 64 + 2) / 2 + 1) * sizeof(double); };
+  auto ldsNeed = [&](int nS) { return (size_t)(p.NSm - nGRows * T + nS * T + 8 + 28   // the exchange rows keep no cells in LDS
+                                                   + T / 64 + (T / 64 + 2) / 2 + 1 + 2) * sizeof(double); };
 
   std::vector<int> rowOfState;
   std::vector<Type> bestCaps;
   {
-    // out-degrees in ascending order, per kind, for the quantile shapes
+    // out-degrees in ascending order, per kind, for the quantile shapes (of the largest member: the others fit below it)
     std::vector<int> outS, outP, outPlainP;   // outPlainP: plain states without null in-edges
-    for (int j = 0; j < N; ++j) {
-      (type[j][1] ? outS : outP).push_back(type[j][0]);
-      if (!type[j][1] && !type[j][2]) outPlainP.push_back(type[j][0]);
+    {
+      std::vector<std::vector<int>> oS(G), oP(G), oPP(G);
+      for (int j = 0; j < N; ++j) {
+        if (isG[j]) continue;
+        (type[j][1] ? oS : oP)[part[j]].push_back(type[j][0]);
+        if (!type[j][1] && !type[j][2]) oPP[part[j]].push_back(type[j][0]);
+      }
+      auto merge = [&](std::vector<std::vector<int>>& per, std::vector<int>* out, bool everyMember) {
+        // element i = the largest i-th smallest out-degree of any member: a row shaped for it serves every member;
+        // everyMember: only as many elements as the smallest member has (a census every member must meet)
+        size_t n = everyMember ? (size_t)-1 : 0;
+        for (auto& v : per) { std::sort(v.begin(), v.end()); n = everyMember ? std::min(n, v.size()) : std::max(n, v.size()); }
+        out->assign(n, 0);
+        for (size_t i = 0; i < n; ++i)
+          for (auto& v : per)
+            if (i < v.size()) (*out)[i] = std::max((*out)[i], v[i]);
+      };
+      merge(oS, &outS, false);
+      merge(oP, &outP, false);
+      merge(oPP, &outPlainP, true);
     }
-    std::sort(outS.begin(), outS.end());
-    std::sort(outP.begin(), outP.end());
-    std::sort(outPlainP.begin(), outPlainP.end());
-    const int minS = (nNullDest + T - 1) / T;
+    const int minS = (nNullDestMax + T - 1) / T;
+    const int KN = K - nGRows;                       // rows behind the G rows
+    if (KN < 1) return no("the exchange rows leave no room");
     double bestScore = -1;
     std::string why = "no row program fits";
+    long biggest = 0;
+    for (int g = 0; g < G; ++g) biggest = std::max(biggest, (long)walkOf[g].size());
     // K is even (lattice pairs); when the states fit K-1 rows the last one may stay empty and
     // costs nothing in a sweep -- tried both ways
-    for (int KU = K; KU >= std::max(1, K - 1); --KU)
-    for (int nS = minS; nS <= std::min(KU, minS + 2); ++nS) {
+    for (int KU = K; KU >= std::max(1 + nGRows, K - 1); --KU)
+    for (int nS = minS; nS <= std::min(KU - nGRows, minS + 2); ++nS) {
       if (ldsNeed(nS) > kTierALdsLimit) { why = "LDS working set " + std::to_string(ldsNeed(nS)) + " B exceeds one CU"; continue; }
-      if ((size_t)KU * T < (size_t)N) continue;
+      if ((long)KU * T < biggest) continue;
+      const int KUN = KU - nGRows;
       for (int groups = 1; groups <= std::max(1, std::min(3, nS)); ++groups) {
         for (int ascending = 0; ascending < 2; ++ascending)
         for (int plainRows = 0; plainRows < 2; ++plainRows)
@@ -230,14 +335,15 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
           std::vector<int> isS(K, 0);
           for (int g = 0, left = nS; g < groups && nS > 0; ++g) {
             const int len = left / (groups - g);
-            const int at = g * KU / groups;
-            for (int i = 0; i < len; ++i) isS[std::min(KU - 1, at + i)] = 1;
+            const int at = g * KUN / groups;
+            for (int i = 0; i < len; ++i) isS[nGRows + std::min(KUN - 1, at + i)] = 1;
             left -= len;
           }
           if (std::accumulate(isS.begin(), isS.end(), 0) != nS) continue;   // runs collided
           std::vector<Type> caps(K);
           int seenS = 0, seenP = 0, nPlainRows = 0;
           for (int k = 0; k < K; ++k) {
+            if (k < nGRows) { caps[k] = Type{std::max(maxOutG, maxOut), 1, 1, 0xff, 1}; continue; }
             const std::vector<int>& sorted = isS[k] ? outS : outP;
             int& seen = isS[k] ? seenS : seenP;
             int cap = maxOut;
@@ -252,7 +358,7 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
               const size_t have = (size_t)(std::upper_bound(outPlainP.begin(), outPlainP.end(), cap) - outPlainP.begin());
               if (have >= (size_t)(nPlainRows + 1) * T) { generic = 0; ++nPlainRows; }
             }
-            caps[k] = k < KU ? Type{cap, isS[k], generic, 0xff} : Type{-1, -1, -1, 0};   // closed rows admit nothing
+            caps[k] = k < KU ? Type{cap, isS[k], generic, 0xff, 0} : Type{-1, -1, -1, 0, -1};   // closed rows admit nothing
             ++seen;
           }
           if (typedS && nS > 0) {
@@ -261,6 +367,7 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
             // what is left over stays open to every class
             std::array<long, 8> cnt{};
             for (int j = 0; j < N; ++j) if (type[j][1]) ++cnt[(size_t)type[j][3]];
+            for (auto& c : cnt) c = (c + G - 1) / G;
             std::vector<int> sRows;
             for (int k = 0; k < KU; ++k) if (isS[k]) sRows.push_back(k);
             std::vector<int> order{0, 1, 2, 3};
@@ -272,7 +379,12 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
             }
           }
           std::vector<int> rows;
-          if (!deal(caps, &rows)) continue;
+          if (!deal(caps, &rows)) {
+            if (getenv("DNAS_PLAN_DEBUG"))
+              fprintf(stderr, "plan candidate: rows %d S-rows %d groups %d ascending %d plain %d typedS %d -> states do not fit\n", KU, nS, groups,
+                      ascending, plainRows, typedS);
+            continue;
+          }
           int reads = 0, back = 0, entries = 0;
           const double sc = score(rows, &reads, &back, &entries);
           if (getenv("DNAS_PLAN_DEBUG"))
@@ -299,10 +411,16 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
   {
     auto clsOf = [&](int j) { int c = -2; for (int e : outOf[j]) c = c == -2 ? edges[e].sc : (c == edges[e].sc ? c : -1); return c; };
     auto kindOf = [&](int j) { int k = -1; for (int e : outOf[j]) { const int q = edges[e].isNull ? 2 : 1; k = k < 0 ? q : (k == q ? q : 0); } return k; };
+    auto rowEntries = [&]() {
+      std::vector<int> nOut(K, 0);
+      for (int j = 0; j < N; ++j) nOut[rowOfState[j]] = std::max(nOut[rowOfState[j]], type[j][0]);
+      return nOut;
+    };
     for (int attr = 0; attr < 2; ++attr) {
-      std::vector<int> fill(K, 0);
-      for (int j = 0; j < N; ++j) ++fill[rowOfState[j]];
-      // what each row has in common right now (-1 / 0: mixed), per attribute
+      std::vector<int> fill((size_t)G * K, 0);
+      for (int j = 0; j < N; ++j) ++fill[(size_t)part[j] * K + rowOfState[j]];
+      std::vector<int> nOutNow = rowEntries();
+      // what each row has in common right now (-1 / 0: mixed), per attribute -- over all members: they share the program
       auto common = [&](int k) {
         int c = -2;
         for (int j = 0; j < N; ++j)
@@ -319,18 +437,19 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
         if (byVal.size() < 2) continue;
         size_t most = 0, total = 0;
         for (const auto& kv : byVal) { most = std::max(most, kv.second.size()); total += kv.second.size(); }
-        if (total - most > (size_t)T / 50) continue;
+        if (total - most > (size_t)G * T / 50) continue;
         for (const auto& kv : byVal) {
           if (kv.second.size() == most) continue;
           for (int j : kv.second) {
             for (int k2 = 0; k2 < K; ++k2) {
-              if (k2 == k || fill[k2] >= T) continue;
+              if (k2 == k || fill[(size_t)part[j] * K + k2] >= T) continue;
               const Type& c2 = bestCaps[k2];
-              if (type[j][0] > c2[0] || type[j][1] > c2[1] || type[j][2] > c2[2] || !((c2[3] >> type[j][3]) & 1)) continue;
+              if (type[j][0] > c2[0] || type[j][1] > c2[1] || type[j][2] > c2[2] || !((c2[3] >> type[j][3]) & 1) || type[j][4] != c2[4]) continue;
+              if (type[j][0] > nOutNow[k2]) continue;      // would grow the row's entry registers
               const int have = common(k2);
               const int mine = attr == 0 ? clsOf(j) : kindOf(j);
               if (!(have == (attr == 0 ? -1 : 0) || have == mine || have == -2)) continue;   // would spoil k2
-              rowOfState[j] = k2; --fill[k]; ++fill[k2];
+              rowOfState[j] = k2; --fill[(size_t)part[j] * K + k]; ++fill[(size_t)part[j] * K + k2];
               break;
             }
           }
@@ -349,21 +468,22 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
   // inside one thread), then the other lane of that wave with the same residue, then any lane
   // of the wave whose half does not yet use that bank pair, then the same residue elsewhere.
   std::vector<int> laneOf(N, -1);
-  std::vector<std::vector<int>> rowMembers(K);                    // states of each row
-  for (int j = 0; j < N; ++j) { laneOf[j] = (int)rowMembers[rowOfState[j]].size(); rowMembers[rowOfState[j]].push_back(j); }
+  std::vector<std::vector<int>> rowMembers((size_t)G * K);                    // states of each (member, row)
+  auto bucket = [&](int j) { return (size_t)part[j] * K + rowOfState[j]; };
+  for (int j = 0; j < N; ++j) { laneOf[j] = (int)rowMembers[bucket(j)].size(); rowMembers[bucket(j)].push_back(j); }
   auto leadOf = [&](int j) {
     int any = -1;
     for (int e : inOf[j]) {
       const int s = edges[e].src;
-      if (s == j) continue;
+      if (s == j || part[s] != part[j]) continue;
       if (rowOfState[s] < rowOfState[j]) return s;
       if (any < 0) any = s;
     }
     return any;
   };
   for (int pass = 0; pass < 2; ++pass) {
-    for (int k = 0; k < K; ++k) {
-      const std::vector<int>& mem = rowMembers[k];
+    for (size_t b = 0; b < rowMembers.size(); ++b) {
+      const std::vector<int>& mem = rowMembers[b];
       if (mem.empty()) continue;          // padding row
       const int n = (int)mem.size();
       std::vector<char> lanesFree(T, 1);
@@ -404,9 +524,11 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
   }
 
   // row shapes as used, S stripes
-  p.rows.assign(K, RowShape{0, -1, -1, -2, 0});   // kind / cls: -1 / -2 = no entry seen yet
-  std::vector<int> needS(K, 0);
+  p.rows.assign(K, RowShape{0, -1, -1, -2, 0, -1, -1});   // kind / cls / gOut: -1 / -2 / -1 = no entry seen yet
+  std::vector<int> needS(K, 0), rowIsG(K, 0);
   long real = 0;
+  for (int j = 0; j < N; ++j) rowIsG[rowOfState[j]] |= isG[j];
+  for (int k = 0; k < nGRows; ++k) rowIsG[k] = 1;           // (also when no state sits there)
   for (int j = 0; j < N; ++j) {
     RowShape& r = p.rows[rowOfState[j]];
     r.nOut = std::max(r.nOut, type[j][0]);
@@ -414,17 +536,33 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
       const int kind = edges[e].isNull ? 2 : 1;
       r.kind = r.kind < 0 ? kind : (r.kind == kind ? kind : 0);
       r.cls = r.cls == -2 ? edges[e].sc : (r.cls == edges[e].sc ? r.cls : -1);
+      const int go = rowIsG[rowOfState[edges[e].dst]] ? 1 : 0;
+      r.gOut = r.gOut < 0 ? go : (r.gOut == go ? go : 2);
+      if (!go && part[edges[e].dst] != part[j]) return no("internal: edge between members into an LDS row");
     }
     needS[rowOfState[j]] |= type[j][1];
     real += type[j][0];
   }
   p.nSRows = 0;
-  for (int k = 0; k < K; ++k) if (needS[k]) p.rows[k].sIdx = p.nSRows++;
-  for (int k = 0; k < K; ++k) if (rowMembers[k].empty()) p.rows[k].nOut = -1;   // the kernel skips the row
-  for (RowShape& r : p.rows) { if (r.kind < 0) r.kind = 0; if (r.cls == -2) r.cls = -1; }
   for (int k = 0; k < K; ++k) {
-    bool full = (int)rowMembers[k].size() == T;
-    for (int j : rowMembers[k]) full = full && type[j][0] == p.rows[k].nOut;
+    if (rowIsG[k]) {
+      if (k >= nGRows) return no("internal: exchange state outside the exchange rows");
+      p.rows[k].gIdx = k;
+    } else if (needS[k]) {
+      p.rows[k].sIdx = p.nSRows++;
+    }
+  }
+  std::vector<char> rowUsed(K, 0);
+  for (int j = 0; j < N; ++j) rowUsed[rowOfState[j]] = 1;
+  for (int k = 0; k < K; ++k) if (!rowUsed[k]) p.rows[k].nOut = -1;   // the kernel skips the row
+  for (RowShape& r : p.rows) { if (r.kind < 0) r.kind = 0; if (r.cls == -2) r.cls = -1; if (r.gOut < 0) r.gOut = 0; }
+  for (int k = 0; k < K; ++k) {
+    bool full = true;
+    for (int g = 0; g < G; ++g) {
+      const std::vector<int>& mem = rowMembers[(size_t)g * K + k];
+      full = full && (int)mem.size() == T;
+      for (int j : mem) full = full && type[j][0] == p.rows[k].nOut;
+    }
     p.rows[k].full = full ? 1 : 0;
   }
   p.ldsBytes = ldsNeed(p.nSRows);
@@ -432,70 +570,99 @@ TierAPlan buildTierAPlan(const dnas_flat_model& fm) {
   int nEnt = 0;
   std::vector<int> rowOff(K, 0);
   for (int k = 0; k < K; ++k) { rowOff[k] = nEnt; nEnt += std::max(p.rows[k].nOut, 0); }
+  if (nEnt > kMaxEntries) return no("row shapes need " + std::to_string(nEnt) + " entry registers per thread");
   p.nEntries = std::max(nEnt, 1);
-  p.fillRatio = nEnt ? (double)real / ((double)nEnt * T) : 1.0;
+  p.fillRatio = nEnt ? (double)real / ((double)nEnt * T * G) : 1.0;
 
-  // two index spaces: LDS index row*T + lane (consecutive lanes -> consecutive bank pairs), and
-  // the lattice slot (row/2)*2T + 2*lane + (row&1) used in HBM and by the traceback
+  // index spaces: a member's LDS index row*T + lane (consecutive lanes -> consecutive bank pairs), and
+  // the lattice slot member*K*T + (row/2)*2T + 2*lane + (row&1) used in HBM and by the traceback
+  p.memberOf.assign(part.begin(), part.end());
   p.slotOf.assign(N, -1);
-  p.stateOf.assign(p.NS, -1);       // by LDS index
+  p.stateOf.assign((size_t)p.NS, -1);       // by (member*K + row)*T + lane
   for (int j = 0; j < N; ++j) {
     const int row = rowOfState[j], lane = laneOf[j];
-    p.stateOf[row * T + lane] = j;
-    p.slotOf[j] = (row >> 1) * 2 * T + 2 * lane + (row & 1);
+    p.stateOf[((size_t)part[j] * K + row) * T + lane] = j;
+    p.slotOf[j] = part[j] * p.NSm + (row >> 1) * 2 * T + 2 * lane + (row & 1);
   }
 
   // entries, one per out-edge (layout: viterbi_tiera.hip).  0: no edge.
   const unsigned dcBase = (unsigned)p.nSRows * T * 8 + 64;     // byte address of DC[0]: behind the S stripes and a pad
   if (p.nSRows * T > 0x1ffc) return no("more than 8188 S cells");
-  p.entTab.assign((size_t)p.nEntries * T, 0u);
+  p.entTab.assign((size_t)G * p.nEntries * T, 0u);
   long fwd = 0, fwdSameWave = 0;
   for (int j = 0; j < N; ++j) {
     const int row = rowOfState[j], lane = laneOf[j];
     for (size_t i = 0; i < outOf[j].size(); ++i) {
       const Edge& e = edges[outOf[j][i]];
       const int drow = rowOfState[e.dst], dlane = laneOf[e.dst];
-      unsigned ent = (unsigned)e.sc | (dcBase + (unsigned)(drow * T + dlane) * 8u);
-      if (e.isNull) {
-        if (p.rows[drow].sIdx < 0) return no("internal: null edge into a row without S cells");
-        ent |= (unsigned)(p.rows[drow].sIdx * T + dlane) << 19;
+      unsigned ent;
+      if (rowIsG[drow]) {
+        // exchange cell (dst member, G row, lane):  [0:2) class | bit 2 | [3:23) cell | bit 23 null edge | [24:26) emitted base
+        const unsigned cell = (unsigned)((part[e.dst] * nGRows + p.rows[drow].gIdx) * T + dlane);
+        ent = (unsigned)e.sc | 4u | (cell << 3) | (e.isNull ? 1u << 23 : (unsigned)(e.base & 3) << 24);
       } else {
-        ent |= (0x1ffcu | (unsigned)(e.base & 3)) << 19;
+        ent = (unsigned)e.sc | (dcBase + (unsigned)((drow - nGRows) * T + dlane) * 8u);
+        if (e.isNull) {
+          if (p.rows[drow].sIdx < 0) return no("internal: null edge into a row without S cells");
+          ent |= (unsigned)(p.rows[drow].sIdx * T + dlane) << 19;
+        } else {
+          ent |= (0x1ffcu | (unsigned)(e.base & 3)) << 19;
+        }
       }
-      p.entTab[(size_t)(rowOff[row] + (int)i) * T + lane] = ent;
-      if (drow > row) { ++fwd; if (dlane / 64 == lane / 64) ++fwdSameWave; }
+      p.entTab[((size_t)part[j] * p.nEntries + (size_t)(rowOff[row] + (int)i)) * T + lane] = ent;
+      if (drow > row && part[e.dst] == part[j]) { ++fwd; if (dlane / 64 == lane / 64) ++fwdSameWave; }
     }
   }
   p.sameWave = fwd ? (double)fwdSameWave / (double)fwd : 1.0;
 
   // meta: mdl | ctx << 4 | bit29 real state | bit30 reference's last state | bit31 reference's state 0
-  p.metaTab.assign((size_t)K * T, 0);
-  for (int k = 0; k < K; ++k)
-    for (int t = 0; t < T; ++t) {
-      const int j = p.stateOf[k * T + t];
-      unsigned meta = 0;
-      if (j >= 0) {
-        meta = fm.mdl[j] & 15u;
-        for (int q = 0; q < fm.mdl[j] && q < 8; ++q) meta |= (unsigned)(fm.ctx[(size_t)j * D + q] & 3u) << (4 + 2 * q);
-        if (j == 0) meta |= 0x80000000u;
-        if (j == N - 1) meta |= 0x40000000u;
-        meta |= 0x20000000u;   // slot holds a real state
-      }
-      p.metaTab[(size_t)k * T + t] = meta;
+  p.metaTab.assign((size_t)G * K * T, 0);
+  for (size_t idx = 0; idx < p.metaTab.size(); ++idx) {
+    const int j = p.stateOf[idx];
+    unsigned meta = 0;
+    if (j >= 0) {
+      meta = fm.mdl[j] & 15u;
+      for (int q = 0; q < fm.mdl[j] && q < 8; ++q) meta |= (unsigned)(fm.ctx[(size_t)j * D + q] & 3u) << (4 + 2 * q);
+      if (j == 0) meta |= 0x80000000u;
+      if (j == N - 1) meta |= 0x40000000u;
+      meta |= 0x20000000u;   // slot holds a real state
     }
+    p.metaTab[idx] = meta;
+  }
 
   std::ostringstream rows, defs;
   for (int k = 0; k < K; ++k) {
     if (k) rows << ",";
-    rows << "{" << p.rows[k].nOut << "," << p.rows[k].sIdx << "," << p.rows[k].kind << "," << p.rows[k].cls << "," << p.rows[k].full << "}";
+    rows << "{" << p.rows[k].nOut << "," << p.rows[k].sIdx << "," << p.rows[k].kind << "," << p.rows[k].cls << "," << p.rows[k].full << ","
+         << p.rows[k].gIdx << "," << p.rows[k].gOut << "}";
   }
-  defs << "-DDNAS_T=" << T << "\n-DDNAS_K=" << K << "\n-DDNAS_D=" << D << "\n-DDNAS_NS=" << p.NS << "\n-DDNAS_SROWS=" << p.nSRows
-       << "\n-DDNAS_NCLS=" << p.nClasses << "\n-DDNAS_ROWS=" << rows.str();
+  defs << "-DDNAS_T=" << T << "\n-DDNAS_K=" << K << "\n-DDNAS_D=" << D << "\n-DDNAS_NS=" << p.NSm << "\n-DDNAS_SROWS=" << p.nSRows
+       << "\n-DDNAS_NCLS=" << p.nClasses << "\n-DDNAS_G=" << G << "\n-DDNAS_GROWS=" << nGRows << "\n-DDNAS_ROWS=" << rows.str();
   p.defines = defs.str();
   p.key = "T" + std::to_string(T) + "K" + std::to_string(K) + "D" + std::to_string(D) + "S" + std::to_string(p.nSRows) + "C" +
-          std::to_string(p.nClasses) + "R" + rows.str();
+          std::to_string(p.nClasses) + "G" + std::to_string(G) + "X" + std::to_string(nGRows) + "R" + rows.str();
   p.ok = true;
   return p;
+}
+
+}  // namespace
+
+TierAPlan buildTierAPlan(const dnas_flat_model& fm) { return buildPlan(fm, 1); }
+
+TierAPlan buildClusterPlan(const dnas_flat_model& fm, int G) {
+  if (G < 2) { TierAPlan p; p.whyNot = "a cluster has at least two members"; return p; }
+  return buildPlan(fm, G);
+}
+
+TierAPlan buildSmallestClusterPlan(const dnas_flat_model& fm, int gMin) {
+  TierAPlan last;
+  const int lo = std::max(2, std::max(gMin, (int)(((long)fm.n_states * 100 / 93 + (long)kTierAMaxRows * kTierAThreads - 1) / ((long)kTierAMaxRows * kTierAThreads))));
+  for (int G = lo; G <= kTierCMaxMembers; ++G) {
+    last = buildPlan(fm, G);
+    if (last.ok) return last;
+  }
+  if (last.whyNot.empty()) last.whyNot = "more than " + std::to_string(kTierCMaxMembers) + " work-groups per read";
+  return last;
 }
 
 }  // namespace dnas

@@ -1,16 +1,23 @@
-// Tier-A schedule: how one machine's states and edges are laid over the 1024 threads of
-// the register/LDS-resident fill kernel (csrc/viterbi_tiera.hip).  Pure host code.
+// Tier-A / tier-C schedule: how one machine's states and edges are laid over the 1024 threads of
+// the register/LDS-resident fill kernel (csrc/viterbi_tiera.hip) -- of ONE work-group (tier A,
+// machines that fit one CU) or of a CLUSTER of G work-groups that share a read (tier C, machines
+// beyond one CU).  Pure host code.
 //
-//  * every state gets a place = (row, thread); a thread evaluates its rows in order inside a
+//  * every state gets a place = (member, row, thread); a thread evaluates its rows in order inside a
 //    sweep, and keeps the S and D cells of its states in registers
-//  * every state owns an LDS accumulator DC[row*T + thread] that its in-edges are pushed into
-//    (ds_max_f64), and -- if it has null in-edges -- a second one, SC, in a stripe of T cells
-//    that its row shares ("S rows")
+//  * every state owns an accumulator DC that its in-edges are pushed into with an atomic fp64 max, and
+//    -- if it has null in-edges -- a second one, SC:
+//      - a state whose in-edges all come from its own member: LDS cells DC[row*T + thread] and SC in a
+//        stripe of T cells that its row shares ("S rows"), ds_max_f64
+//      - a state with an in-edge from another member of the cluster: cells in the cluster's exchange
+//        buffer in global memory ("G rows"), global_atomic_max_f64 at agent scope; its owner reads them
+//        with agent-scope loads.  ALL in-edges of such a state go through the exchange buffer.
 //  * a state's OUT-edges become per-thread 32-bit entries (kept in registers by the kernel):
 //      emit edge  D(dst) >= max(D+delExtend, S+delOpen) + score        (viterbi.cpp:123-125)
 //                 and, between columns, S(dst) >= S + score + noGap + sub   (viterbi.cpp:92-95)
 //      null edge  D(dst) >= D + score,  S(dst) >= S + score             (viterbi.cpp:137-151)
-//  * the per-row maxima (out-edges, needs an S cell) form the row shape the kernel is compiled for
+//  * the per-row maxima (out-edges, needs an S cell, G row) form the row shape the kernel is compiled
+//    for; the members of a cluster share ONE row program (one code object), only their tables differ
 #pragma once
 #include <cstdint>
 #include <string>
@@ -23,32 +30,47 @@ namespace dnas {
 // per row: out-edge entries per state (-1: row left empty), the row's S stripe (-1: no state of the row has
 // null in-edges), and what all entries of the row have in common, which the kernel then does not decode per
 // lane: kind 1 = emit edges only, 2 = null edges only, 0 = both; cls = the common score class or -1;
-// full = every lane of the row holds a state with exactly nOut out-edges (no entry is empty)
-struct RowShape { int nOut, sIdx, kind, cls, full; };
+// full = every lane of the row holds a state with exactly nOut out-edges (no entry is empty);
+// gIdx = ordinal of the row among the G rows (accumulators in the exchange buffer) or -1;
+// gOut = 0: every entry of the row points into LDS, 1: every entry into the exchange buffer, 2: mixed
+struct RowShape { int nOut, sIdx, kind, cls, full, gIdx, gOut; };
 
 struct TierAPlan {
   bool ok = false;
   std::string whyNot;
-  int T = 1024, K = 0, D = 0, N = 0, NS = 0, nSRows = 0, nClasses = 1, nEntries = 0;
+  int T = 1024, K = 0, D = 0, N = 0, nSRows = 0, nClasses = 1, nEntries = 0;
+  int G = 1;                      // work-groups per read (1: tier A)
+  int nGRows = 0;                 // rows whose accumulators live in the exchange buffer (0 when G == 1)
+  int NSm = 0;                    // lattice slots per member (= K*T)
+  int NS = 0;                     // lattice slots per column (= G*K*T)
   std::vector<RowShape> rows;
   std::string defines;            // "-DDNAS_T=.. -DDNAS_K=.. -DDNAS_D=.. -DDNAS_ROWS=.." joined by '\n'
   std::string key;                // cache key of the specialisation
-  std::vector<int32_t> slotOf;    // [N]  state -> lattice slot (row/2)*2T + 2*thread + (row&1)
-  std::vector<int32_t> stateOf;   // [NS] LDS index (row*T + thread) -> state or -1
-  std::vector<uint32_t> entTab;   // [nEntries][T]  out-edges, see viterbi_tiera.hip
-  std::vector<uint32_t> metaTab;  // [K][T]  mdl | ctx<<4 | flags
+  std::vector<int32_t> memberOf;  // [N]  state -> member of the cluster
+  std::vector<int32_t> slotOf;    // [N]  state -> lattice slot member*NSm + (row/2)*2T + 2*thread + (row&1)
+  std::vector<int32_t> stateOf;   // [G*K*T] index (member*K + row)*T + thread -> state or -1
+  std::vector<uint32_t> entTab;   // [G][nEntries][T]  out-edges, see viterbi_tiera.hip
+  std::vector<uint32_t> metaTab;  // [G][K][T]  mdl | ctx<<4 | flags
   double score[4] = {0, 0, 0, 0};
   size_t ldsBytes = 0;
   double fillRatio = 0;           // real entries / padded entries
-  int sweepReads = 0;             // LDS reads per thread and sweep (own cells)
-  int backEdgesOnWalk = 0;        // most backward edges (destination row <= source row) on any walk of 30 edges
+  int sweepReads = 0;             // accumulator reads per thread and sweep (own cells)
+  int backEdgesOnWalk = 0;        // most backward edges (destination row <= source row, or another member) on any walk of 30 edges
   double sameWave = 0;            // share of forward edges whose ends sit in the same wave
+  double crossEdges = 0;          // share of edges that go through the exchange buffer
+  long exchangeCells() const { return (long)G * nGRows * T; }   // cells of one exchange array
 };
 
 constexpr int kTierAThreads = 1024;
 constexpr int kTierAMaxRows = 14;
+constexpr int kTierCMaxMembers = 32;                  // one XCD
 constexpr size_t kTierALdsLimit = 160 * 1024 - 1024;  // leave room for the static reduction buffer
 
+// One work-group per read; fails (ok = false) when the machine does not fit one CU.
 TierAPlan buildTierAPlan(const dnas_flat_model& fm);
+// G work-groups per read (G >= 2); fails when the states do not fit G CUs or no common row program exists.
+TierAPlan buildClusterPlan(const dnas_flat_model& fm, int G);
+// The smallest cluster that fits (tries G = gMin .. kTierCMaxMembers).
+TierAPlan buildSmallestClusterPlan(const dnas_flat_model& fm, int gMin = 2);
 
 }  // namespace dnas

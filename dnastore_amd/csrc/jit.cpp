@@ -7,6 +7,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <sstream>
 #include <stdexcept>
@@ -39,11 +40,33 @@ std::string libraryDir() {
   return ".";
 }
 
-std::vector<char> jitCompile(const std::string& sourcePath, const std::string& defines, const std::string& key) {
-  const std::string src = slurp(sourcePath);
+// csrc/viterbi_tiera.hip travels INSIDE the library (the Makefile assembles it in with .incbin, see
+// tiera_embed.S): a maintainer who installs only libdnastore_amd.so still gets the tier-A/C kernel.
+extern "C" const char dnas_tiera_source[];
+extern "C" const char dnas_tiera_source_end[];
+
+std::string tieraSource() {
+  if (const char* path = getenv("DNAS_TIERA_SRC")) return slurp(path);   // kernel development: compile this file instead
+  return std::string(dnas_tiera_source, (size_t)(dnas_tiera_source_end - dnas_tiera_source));
+}
+
+std::string kernelCacheDir() {
+  if (const char* dir = getenv("DNAS_KCACHE_DIR")) return dir;
+  return libraryDir() + "/kcache";
+}
+
+#ifndef DNAS_ARCH
+#define DNAS_ARCH "gfx950"
+#endif
+
+std::vector<char> jitCompile(const std::string& defines, const std::string& key) {
+  const std::string src = tieraSource();
+  int rtcMajor = 0, rtcMinor = 0;
+  (void)hiprtcVersion(&rtcMajor, &rtcMinor);
   char name[64];
-  snprintf(name, sizeof name, "%016llx", (unsigned long long)fnv1a(src, fnv1a(defines + "|" + key)));
-  const std::string cacheDir = libraryDir() + "/kcache";
+  snprintf(name, sizeof name, "%016llx",
+           (unsigned long long)fnv1a(src, fnv1a(defines + "|" + key + "|" DNAS_ARCH "|hiprtc" + std::to_string(rtcMajor) + "." + std::to_string(rtcMinor))));
+  const std::string cacheDir = kernelCacheDir();
   const std::string cachePath = cacheDir + "/tiera_" + name + ".hsaco";
   {
     std::ifstream in(cachePath, std::ios::binary);
@@ -52,7 +75,7 @@ std::vector<char> jitCompile(const std::string& sourcePath, const std::string& d
       if (!code.empty()) return code;
     }
   }
-  std::vector<std::string> opts{"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17"};
+  std::vector<std::string> opts{"--offload-arch=" DNAS_ARCH, "-O3", "-ffp-contract=off", "-std=c++17"};
   {
     std::stringstream ss(defines);
     std::string line;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cctype>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
@@ -18,6 +19,7 @@
 extern "C" __global__ void viterbi_fill_kernel(DevModel, const uint8_t*, const uint64_t*, const int32_t*,
                                                const uint64_t*, double*, double*, unsigned long long*, int);
 extern "C" __global__ void expand_lattice_kernel(DevModel, const uint8_t*, const double*, double*);
+extern "C" __global__ void fill_neginf_kernel(double*, size_t);
 extern "C" __global__ void viterbi_traceback_kernel(DevModel, const uint8_t*, const uint64_t*, const int32_t*,
                                                     const uint64_t*, const double*, char*, const uint64_t*,
                                                     uint32_t*, uint8_t*, int);
@@ -48,11 +50,26 @@ struct TierALaunch {
   double* arena;
   double* outLoglike;
   unsigned long long* roundsTotal;
+  // tier C (a cluster of work-groups per read): exchange buffers, sync blocks, clusters in this launch, reads in this launch
+  double* xbuf;
+  unsigned* syncWords;
+  int nClusters;
+  int nReads;
+  unsigned long long timeoutTicks;
 };
 
 struct dnas_model {
   int device = 0;
-  int tier = 0;                 // 1 = tier A (register/LDS-resident JIT kernel), 0 = tier B (global-memory kernel)
+  int tier = 0;                 // 1 = tier A (register/LDS-resident JIT kernel, one work-group per read), 2 = tier C (the same
+                                // kernel, a cluster of work-groups per read), 0 = tier B (global-memory kernel)
+  int maxClusters = 1;          // tier C: clusters that fit the GPU at once
+  double* dXbuf = nullptr;      // tier C: exchange buffers, one per cluster
+  unsigned* dSync = nullptr;    // tier C: sync blocks (64 u32 per cluster)
+  size_t xStride = 0;           // doubles per cluster in dXbuf
+  unsigned long long timeoutTicks = 0;
+  std::vector<unsigned> syncCheck;   // host copies of the sync blocks of every launch of the last call (watchdog, placement census)
+  size_t syncLaunches = 0;
+  unsigned clustersSeen = 0, clustersSplit = 0;   // last call: clusters that ran, clusters whose members sat on more than one XCD
   std::string tierNote;
   dnas::TierAPlan plan;
   hipModule_t module = nullptr;
@@ -110,6 +127,15 @@ int collect_stats(dnas_model* m) {
   HIP_TRY(hipMemcpy(&r, m->dRounds, sizeof r, hipMemcpyDeviceToHost));
   m->stats.rounds = (int64_t)r;
   m->statsPending = false;
+  if (m->tier == 2) {
+    unsigned xccMixed = 0, clusters = 0;
+    for (size_t c = 0; c * 64 < m->syncCheck.size(); ++c) {
+      const unsigned* w = m->syncCheck.data() + c * 64;
+      if (w[1]) return dnas::fail(DNAS_E_DEVICE, "tier C: a cluster did not agree on a lattice column within the watchdog time (launch aborted)");
+      if (w[40]) { ++clusters; if (w[40] & (w[40] - 1)) ++xccMixed; }
+    }
+    m->clustersSeen = clusters; m->clustersSplit = xccMixed;
+  }
   return DNAS_OK;
 }
 
@@ -118,8 +144,30 @@ int collect_stats(dnas_model* m) {
 extern "C" int dnas_has_device_code(void) { return 1; }
 
 extern "C" int dnas_model_create(const dnas_flat_model* fm, int device_id, size_t arena_bytes, dnas_model** out) {
+  return dnas_model_create_ex(fm, device_id, arena_bytes, nullptr, out);
+}
+
+// options: "key=value,key=value"; keys tier (A|B|C), cluster (work-groups per read), max_clusters, max_slots,
+// cluster_timeout_s.  A key that is absent falls back to the environment variable DNAS_<KEY>.
+extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, size_t arena_bytes, const char* options,
+                                    dnas_model** out) {
   if (!fm || !out) return dnas::fail(DNAS_E_INVALID, "dnas_model_create: null argument");
   *out = nullptr;
+  const std::string optStr = options ? options : "";
+  std::string optHold;
+  auto opt = [&](const char* key) -> const char* {
+    const std::string k = std::string(key) + "=";
+    size_t at = 0;
+    while (at < optStr.size()) {
+      size_t end = optStr.find(',', at);
+      if (end == std::string::npos) end = optStr.size();
+      if (optStr.compare(at, k.size(), k) == 0) { optHold = optStr.substr(at + k.size(), end - at - k.size()); return optHold.c_str(); }
+      at = end + 1;
+    }
+    std::string env = "DNAS_" + std::string(key);
+    for (char& c : env) c = (char)toupper((unsigned char)c);
+    return getenv(env.c_str());
+  };
   if (fm->n_len > kMaxLen) return dnas::fail(DNAS_E_UNSUPPORTED, "pLen longer than 32 entries");
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
@@ -167,19 +215,35 @@ extern "C" int dnas_model_create(const dnas_flat_model* fm, int device_id, size_
     return r;
   };
   {
-    const char* force = getenv("DNAS_TIER");
-    if (force && (force[0] == 'B' || force[0] == 'b')) {
+    // DNAS_TIER=A|B|C forces a tier (and makes its failure an error); DNAS_CLUSTER=<G> forces the cluster size
+    const char* forceOpt = opt("tier");
+    const std::string force = forceOpt ? forceOpt : "";
+    const char want = !force.empty() ? (char)(force[0] & ~0x20) : 0;
+    int wantG = 0;
+    if (const char* s = opt("cluster")) wantG = atoi(s);
+    if (want == 'B') {
       m->tierNote = "tier B forced by DNAS_TIER";
     } else {
-      m->plan = dnas::buildTierAPlan(*fm);
+      std::string whyNotA;
+      if (want != 'C' && wantG < 2) {
+        m->plan = dnas::buildTierAPlan(*fm);
+        if (!m->plan.ok) whyNotA = m->plan.whyNot;
+      } else {
+        m->plan.ok = false;
+        whyNotA = "cluster forced";
+      }
+      if (!m->plan.ok && want != 'A') {
+        m->plan = wantG >= 2 ? dnas::buildClusterPlan(*fm, wantG) : dnas::buildSmallestClusterPlan(*fm);
+        if (!m->plan.ok) m->plan.whyNot = "one work-group: " + whyNotA + "; cluster: " + m->plan.whyNot;
+      }
       if (!m->plan.ok) {
         m->tierNote = "tier B: " + m->plan.whyNot;
+        if (want) return bail(dnas::fail(DNAS_E_UNSUPPORTED, "tier " + force + " was asked for: " + m->plan.whyNot));
       } else {
         try {
           std::string defs = m->plan.defines;
           if (const char* extra = getenv("DNAS_TIERA_DEFS")) defs += std::string("\n") + extra;   // diagnostics, e.g. -DDNAS_STAMP
-          const std::vector<char> code =
-              dnas::jitCompile(dnas::libraryDir() + "/csrc/viterbi_tiera.hip", defs, m->plan.key);
+          const std::vector<char> code = dnas::jitCompile(defs, m->plan.key);
           if (hipModuleLoadData(&m->module, code.data()) != hipSuccess ||
               hipModuleGetFunction(&m->fillA, m->module, "viterbi_fill_tiera") != hipSuccess)
             throw std::runtime_error("hipModuleLoadData/GetFunction failed");
@@ -201,17 +265,39 @@ extern "C" int dnas_model_create(const dnas_flat_model* fm, int device_id, size_
           d.slotOf = m->dSlotOf;
           d.Npad = p.NS;          // lattice row stride = slots
           d.storedLanes = 2;      // tier A keeps S and D in HBM; T lanes are recomputed where needed
-          m->tier = 1;
-          m->tierNote = "tier A: " + p.key;
+          if (p.G == 1) {
+            m->tier = 1;
+            m->tierNote = "tier A: " + p.key;
+          } else {
+            // a cluster lives on one XCD (32 CUs): floor(32 / G) clusters per XCD.  Every cluster owns an exchange
+            // buffer (3 arrays of G * GROWS * T cells + the end-of-read reduction cells) and a sync block.
+            int cus = 256;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id);
+            const int xcds = std::max(1, cus / 32);
+            m->maxClusters = std::max(1, xcds * ((cus / xcds) / p.G));
+            if (const char* s = opt("max_clusters")) m->maxClusters = std::max(1, atoi(s));
+            m->xStride = 3 * (size_t)p.exchangeCells() + 8;
+            if (hipMalloc((void**)&m->dXbuf, m->xStride * (size_t)m->maxClusters * sizeof(double)) != hipSuccess ||
+                hipMalloc((void**)&m->dSync, (size_t)m->maxClusters * 64 * sizeof(unsigned)) != hipSuccess)
+              throw std::runtime_error("tier C exchange buffer allocation failed");
+            double seconds = 2.0;   // watchdog per lattice column (a column takes tens of microseconds)
+            if (const char* s = opt("cluster_timeout_s")) seconds = std::max(0.001, atof(s));
+            m->timeoutTicks = (unsigned long long)(seconds * 1e8);   // s_memrealtime counts at 100 MHz
+            m->tier = 2;
+            m->tierNote = "tier C: " + std::to_string(p.G) + " work-groups per read, " + std::to_string(m->maxClusters) +
+                          " clusters, exchange edges " + std::to_string(p.crossEdges) + ", " + p.key;
+          }
         } catch (const std::exception& e) {
           m->tier = 0;
-          m->tierNote = std::string("tier B: tier A unavailable: ") + e.what();
-          if (getenv("DNAS_TIER")) return bail(dnas::fail(DNAS_E_DEVICE, m->tierNote));   // DNAS_TIER=A: fail loudly
+          m->tierNote = std::string("tier B: tier A/C unavailable: ") + e.what();
+          // no silent fallback: a machine the register/LDS kernel can serve is served by it or not at all,
+          // unless the caller asked for the fallback explicitly (DNAS_ALLOW_TIER_B_FALLBACK=1)
+          if (!getenv("DNAS_ALLOW_TIER_B_FALLBACK")) return bail(dnas::fail(DNAS_E_DEVICE, m->tierNote));
         }
       }
     }
   }
-  if ((rc = uploadEdgeSlots(m->tier == 1 ? m->plan.slotOf.data() : nullptr)) != DNAS_OK) return bail(rc);
+  if ((rc = uploadEdgeSlots(m->tier >= 1 ? m->plan.slotOf.data() : nullptr)) != DNAS_OK) return bail(rc);
   size_t freeB = 0, totalB = 0;
   if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return bail(dnas::fail(DNAS_E_DEVICE, "hipMemGetInfo failed"));
   m->arenaCap = arena_bytes ? arena_bytes : (size_t)((double)freeB * 0.6);
@@ -230,7 +316,8 @@ extern "C" int dnas_model_create(const dnas_flat_model* fm, int device_id, size_
       m->maxSlots = std::max(1, 3 * (cus - 2 * xcds));
     }
   }
-  if (const char* s = getenv("DNAS_MAX_SLOTS")) m->maxSlots = std::max(1, atoi(s));
+  if (m->tier == 2) m->maxSlots = 1 << 20;   // persistent clusters walk any number of reads: a launch is bounded by the arena only
+  if (const char* s = opt("max_slots")) m->maxSlots = std::max(1, atoi(s));
   *out = m;
   return DNAS_OK;
 }
@@ -249,6 +336,8 @@ extern "C" void dnas_model_destroy(dnas_model* m) {
   if (m->dEntTab) (void)hipFree(m->dEntTab);
   if (m->dMetaTab) (void)hipFree(m->dMetaTab);
   if (m->dSlotOf) (void)hipFree(m->dSlotOf);
+  if (m->dXbuf) (void)hipFree(m->dXbuf);
+  if (m->dSync) (void)hipFree(m->dSync);
   if (m->module) (void)hipModuleUnload(m->module);
   if (m->dBatchRead) (void)hipFree(m->dBatchRead);
   if (m->dSlotOff) (void)hipFree(m->dSlotOff);
@@ -365,6 +454,10 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
     HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     m->sync.push_back(e);
   }
+  if (m->tier == 2) {
+    m->syncCheck.assign(nBatches * (size_t)m->maxClusters * 64, 0u);
+    m->syncLaunches = nBatches;
+  }
   const int maskWords = (d.N + 31) / 32 + 1;
   const size_t ldsBytes = 2 * (size_t)maskWords * sizeof(unsigned);
   // slot offsets of odd batches point into the second half
@@ -380,13 +473,32 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
     // the half this batch fills was last read by the traceback of batch b-2
     if (b >= 2) HIP_TRY(hipStreamWaitEvent(m->stream, m->sync[2 * (b - 2) + 1], 0));
     HIP_TRY(hipEventRecord(m->events[4 * b], m->stream));
-    if (m->tier == 1) {
+    if (m->tier >= 1) {
       TierALaunch la{m->argsA, m->dEntTab, m->dMetaTab, d_bases, m->dReadOff, m->dBatchRead + s, m->dSlotOff + s,
-                     m->arena, d_out_loglike, m->dRounds};
+                     m->arena, d_out_loglike, m->dRounds, nullptr, nullptr, 0, nB, 0ull};
+      unsigned grid = (unsigned)nB;
+      if (m->tier == 2) {
+        // a cluster of G work-groups per read, persistent over the reads of the launch.  Blocks b and b + 8 share
+        // an XCD (observed dispatch order; the kernel is correct under any placement): the members of a cluster are
+        // 8 blocks apart, cluster = (b / 8 / G) * 8 + b % 8.
+        const int G = m->plan.G;
+        const int nClusters = std::min(nB, m->maxClusters);
+        la.xbuf = m->dXbuf; la.syncWords = m->dSync; la.nClusters = nClusters; la.timeoutTicks = m->timeoutTicks;
+        grid = (unsigned)(8 * G * ((nClusters + 7) / 8));
+        const size_t nX = m->xStride * (size_t)nClusters;
+        hipLaunchKernelGGL(fill_neginf_kernel, dim3((unsigned)((nX + 255) / 256)), dim3(256), 0, m->stream, m->dXbuf, nX);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemsetAsync(m->dSync, 0, (size_t)nClusters * 64 * sizeof(unsigned), m->stream));
+      }
       size_t laSize = sizeof la;
       void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &la, HIP_LAUNCH_PARAM_BUFFER_SIZE, &laSize, HIP_LAUNCH_PARAM_END};
-      HIP_TRY(hipModuleLaunchKernel(m->fillA, (unsigned)nB, 1, 1, (unsigned)m->plan.T, 1, 1, (unsigned)m->plan.ldsBytes,
+      HIP_TRY(hipModuleLaunchKernel(m->fillA, grid, 1, 1, (unsigned)m->plan.T, 1, 1, (unsigned)m->plan.ldsBytes,
                                     m->stream, nullptr, config));
+      if (m->tier == 2) {
+        // the watchdog words of this launch: [1] of every sync block (checked in dnas_model_sync)
+        HIP_TRY(hipMemcpyAsync(m->syncCheck.data() + b * (size_t)m->maxClusters * 64, m->dSync,
+                               (size_t)std::min(nB, m->maxClusters) * 64 * sizeof(unsigned), hipMemcpyDeviceToHost, m->stream));
+      }
     } else {
       hipLaunchKernelGGL(viterbi_fill_kernel, dim3(nB), dim3(kFillThreads), ldsBytes, m->stream, d, d_bases,
                          (const uint64_t*)m->dReadOff, (const int32_t*)(m->dBatchRead + s),
@@ -524,7 +636,7 @@ extern "C" int dnas_tiera_precompile(const dnas_flat_model* fm, char* note, size
     if (!p.ok) {
       msg = "tier B: " + p.whyNot;
     } else {
-      (void)dnas::jitCompile(dnas::libraryDir() + "/csrc/viterbi_tiera.hip", p.defines, p.key);
+      (void)dnas::jitCompile(p.defines, p.key);
       msg = "tier A: " + p.key + " lds=" + std::to_string(p.ldsBytes) + " fill=" + std::to_string(p.fillRatio) +
             " reads=" + std::to_string(p.sweepReads) + " entries=" + std::to_string(p.nEntries) + " back=" +
             std::to_string(p.backEdgesOnWalk) + " sameWave=" + std::to_string(p.sameWave);
@@ -537,6 +649,65 @@ extern "C" int dnas_tiera_precompile(const dnas_flat_model* fm, char* note, size
 }
 
 extern "C" const char* dnas_model_tier(const dnas_model* m) { return m ? m->tierNote.c_str() : ""; }
+
+// Tier C: compile the cluster kernel for a machine ahead of time (members = 0: the smallest cluster that fits).
+extern "C" int dnas_tierc_precompile(const dnas_flat_model* fm, int32_t members, char* note, size_t note_cap) {
+  if (!fm) return dnas::fail(DNAS_E_INVALID, "null argument");
+  try {
+    const dnas::TierAPlan p = members >= 2 ? dnas::buildClusterPlan(*fm, members) : dnas::buildSmallestClusterPlan(*fm);
+    if (!p.ok) return dnas::fail(DNAS_E_UNSUPPORTED, p.whyNot);
+    (void)dnas::jitCompile(p.defines, p.key);
+    const std::string msg = "tier C: G=" + std::to_string(p.G) + " K=" + std::to_string(p.K) + " exchange rows " + std::to_string(p.nGRows) +
+                            " exchange edges " + std::to_string(p.crossEdges) + " lds=" + std::to_string(p.ldsBytes) + " entries=" +
+                            std::to_string(p.nEntries) + " back=" + std::to_string(p.backEdgesOnWalk) + " " + p.key;
+    if (note && note_cap) { strncpy(note, msg.c_str(), note_cap - 1); note[note_cap - 1] = 0; }
+    return DNAS_OK;
+  } catch (const std::exception& e) {
+    return dnas::fail(DNAS_E_DEVICE, e.what());
+  }
+}
+
+// Analysis / test aid: the tier-C tables of a machine exactly as the kernel receives them (no GPU needed).
+// info[8] = {G, K, T, entries per member, S stripes, exchange rows, 0, 0}; every other output may be NULL:
+// row_shapes[K][7], entries[G][n_entries][T], meta[G][K][T], member_of[N], lds_index[N] = row*T + lane inside
+// the member, lattice_slot[N].
+extern "C" int dnas_tierc_plan(const dnas_flat_model* fm, int32_t members, int32_t* info, int32_t* row_shapes, uint32_t* entries,
+                               size_t entries_cap, uint32_t* meta, int32_t* member_of, int32_t* lds_index, int32_t* lattice_slot) {
+  if (!fm || !info) return dnas::fail(DNAS_E_INVALID, "null argument");
+  try {
+    const dnas::TierAPlan p = members >= 2 ? dnas::buildClusterPlan(*fm, members)
+                                           : (members == 1 ? dnas::buildTierAPlan(*fm) : dnas::buildSmallestClusterPlan(*fm));
+    if (!p.ok) return dnas::fail(DNAS_E_UNSUPPORTED, p.whyNot);
+    info[0] = p.G; info[1] = p.K; info[2] = p.T; info[3] = p.nEntries; info[4] = p.nSRows; info[5] = p.nGRows; info[6] = info[7] = 0;
+    if (row_shapes)
+      for (int k = 0; k < p.K; ++k) {
+        const dnas::RowShape& r = p.rows[k];
+        const int v[7] = {r.nOut, r.sIdx, r.kind, r.cls, r.full, r.gIdx, r.gOut};
+        memcpy(row_shapes + 7 * k, v, sizeof v);
+      }
+    if (entries) {
+      if (entries_cap < p.entTab.size()) return dnas::fail(DNAS_E_INVALID, "entry buffer too small");
+      memcpy(entries, p.entTab.data(), p.entTab.size() * sizeof(uint32_t));
+    }
+    if (meta) memcpy(meta, p.metaTab.data(), p.metaTab.size() * sizeof(uint32_t));
+    if (member_of) memcpy(member_of, p.memberOf.data(), (size_t)p.N * sizeof(int32_t));
+    if (lds_index)
+      for (size_t idx = 0; idx < p.stateOf.size(); ++idx)
+        if (p.stateOf[idx] >= 0) lds_index[p.stateOf[idx]] = (int32_t)(idx % ((size_t)p.K * p.T));
+    if (lattice_slot) memcpy(lattice_slot, p.slotOf.data(), (size_t)p.N * sizeof(int32_t));
+    return DNAS_OK;
+  } catch (const std::exception& e) {
+    return dnas::fail(DNAS_E_DEVICE, e.what());
+  }
+}
+
+// Tier C diagnostics of the last call: clusters that ran, and how many of them had members on more than one XCD.
+extern "C" int dnas_model_cluster_census(dnas_model* m, int32_t* clusters, int32_t* split) {
+  if (!m || !clusters || !split) return dnas::fail(DNAS_E_INVALID, "null argument");
+  if (m->statsPending) return dnas::fail(DNAS_E_INVALID, "call dnas_model_sync first");
+  *clusters = (int32_t)m->clustersSeen; *split = (int32_t)m->clustersSplit;
+  return DNAS_OK;
+}
 
 // Diagnostic: the 8 words of the rounds/stamps buffer of the last call (word 0 = total rounds).
 extern "C" int dnas_model_debug_words(dnas_model* m, unsigned long long* out8) {

@@ -107,6 +107,12 @@ __device__ __forceinline__ double cell_at(const DevModel& m, const double* __res
 
 }  // namespace
 
+// -inf into every cell of the tier-C exchange buffers before a launch.
+extern "C" __global__ void fill_neginf_kernel(double* __restrict__ p, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = kNegInf;
+}
+
 // Test/diagnostic aid: the full (D+2)-lane lattice of one read in reference state order,
 // out[(pos*(D+2)+lane)*N + state], whatever the storage tier.  grid = L+1, any block size.
 extern "C" __global__ void expand_lattice_kernel(DevModel m, const uint8_t* __restrict__ seq, const double* __restrict__ lat,

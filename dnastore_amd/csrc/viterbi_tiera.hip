@@ -21,19 +21,32 @@
 //
 // fp64 throughout, reference operand order, no contraction / fast-math.
 //
+// Machines beyond one CU ("tier C", DNAS_G > 1): a CLUSTER of DNAS_G work-groups shares a read; member g
+// owns a part of the states (host/plan.cpp cuts the machine along its depth-first walk).  Edges inside a
+// member work as above.  A state with an in-edge from another member keeps its accumulators in the
+// cluster's exchange buffer in global memory ("G rows"): offers go there with global_atomic_max_f64 and
+// the owner reads them with agent-scope loads, so the protocol is correct wherever the work-groups run;
+// the launcher places a cluster on one XCD (blockIdx b and b+8 share one) for speed only.  Termination is
+// agreed in two levels: inside a work-group as before, across the cluster through a device-scope epoch
+// GE (bumped after every batch of exchange offers has completed) and one idle word per member.
+//
 // Compile-time parameters (-D):  DNAS_T threads, DNAS_K rows, DNAS_D dup lanes,
-//   DNAS_NS slots (= K*T), DNAS_SROWS S stripes, DNAS_NCLS distinct edge scores,
-//   DNAS_ROWS  brace list of {out-edge entries (-1: row left empty), S stripe or -1, kind, cls, full} per row;
-//              what all entries of a row have in common is not decoded per lane.
+//   DNAS_NS slots per member (= K*T), DNAS_SROWS S stripes, DNAS_NCLS distinct edge scores,
+//   DNAS_G members per cluster, DNAS_GROWS rows with accumulators in the exchange buffer,
+//   DNAS_ROWS  brace list of {out-edge entries (-1: row left empty), S stripe or -1, kind, cls, full, G-row ordinal
+//              or -1, gOut} per row; what all entries of a row have in common is not decoded per lane.
 #ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>   // hiprtc provides the device runtime implicitly
 #endif
 
 #ifndef DNAS_T
-#error "compile with -DDNAS_T= -DDNAS_K= -DDNAS_D= -DDNAS_NS= -DDNAS_SROWS= -DDNAS_NCLS= -DDNAS_ROWS="
+#error "compile with -DDNAS_T= -DDNAS_K= -DDNAS_D= -DDNAS_NS= -DDNAS_SROWS= -DDNAS_NCLS= -DDNAS_G= -DDNAS_GROWS= -DDNAS_ROWS="
 #endif
 
-struct RowShape { int nOut, sIdx, kind, cls, full; };   // kind: 1 emit edges only, 2 null edges only, 0 both; cls: common score class or -1; full: no empty entry
+// kind: 1 emit edges only, 2 null edges only, 0 both; cls: common score class or -1; full: no empty entry;
+// gIdx: ordinal among the rows whose accumulators live in the exchange buffer, or -1; gOut: 0 every entry of
+// the row points into LDS, 1 every entry into the exchange buffer, 2 mixed (bit 2 of the entry tells)
+struct RowShape { int nOut, sIdx, kind, cls, full, gIdx, gOut; };
 constexpr RowShape kRows[DNAS_K] = {DNAS_ROWS};
 
 constexpr bool rowLive(int k) { return kRows[k].nOut >= 0; }      // nOut -1: the plan left the row empty
@@ -57,6 +70,12 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
+
+#ifndef DNAS_G
+#define DNAS_G 1
+#define DNAS_GROWS 0
+#endif
+
 // kernel-argument block (mirrors runtime.hip TierAArgs)
 struct TierAArgs {
   int N;            // real states
@@ -67,16 +86,18 @@ struct TierAArgs {
   double score[4];  // score table, score[0] == 0
 };
 
-// LDS map (bytes):  SC[SROWS*T] | pad | DC[NS] | score[4] | sub[16] | len[8] | red[T/64] | epoch, idle[T/64] (u32)
+// LDS map (bytes):  SC[SROWS*T] | pad | DC[NS - GROWS*T] | score[4] | sub[16] | len[8] | red[T/64] | epoch, idle[T/64], done, ge, abort (u32)
 constexpr int kDCBase = DNAS_SROWS * DNAS_T * 8 + 64;
-constexpr int kTabBase = kDCBase + DNAS_NS * 8;
+constexpr int kTabBase = kDCBase + (DNAS_NS - DNAS_GROWS * DNAS_T) * 8;   // the exchange rows (the first GROWS rows) keep no cells in LDS
 
 // entries (host/plan.cpp packs them), one per out-edge; every field is one or two VALU
-// operations away from its use:
+// operations away from its use.  Destination in LDS:
 //   [0:2)   score class
 //   [3:18)  byte address of the destination's DC cell, >> 3       ->  en & 0x3fff8
 //   [19:32) null edge: index of the destination's SC cell          ->  (en >> 16) & 0xfff8 is its byte address
 //           emit edge: 0x1ffc | emitted base                       ->  en >= 0xffe00000
+// destination in the cluster's exchange buffer (bit 2 set):
+//   [0:2) score class | [3:23) cell index -> en & 0x7ffff8 is its byte offset | bit 23 null edge | [24:26) emitted base
 //   0: no edge
 #define ENT_VALID(e) ((e) != 0u)
 #define ENT_EMIT(e) ((e) >= 0xffe00000u)
@@ -84,6 +105,10 @@ constexpr int kTabBase = kDCBase + DNAS_NS * 8;
 #define ENT_SC(e) (((e) >> 16) & 0xfff8u)
 #define ENT_CLS(e) ((e) & 3u)
 #define ENT_BASE32(e) (((e) >> 14) & 0x60u)   // emitted base * 32: byte offset of its row in the sub table
+#define ENT_GLOBAL(e) (((e) & 4u) != 0u)
+#define ENT_GCELL(e) ((e) & 0x7ffff8u)
+#define ENT_GNULL(e) (((e) & 0x800000u) != 0u)
+#define ENT_GBASE32(e) (((e) >> 19) & 0x60u)
 
 // v_max_f64 directly: no NaN can occur here (only -inf + finite / -inf + -inf), so the
 // canonicalising copies the compiler would add around fmax() are pure overhead
@@ -101,6 +126,18 @@ __device__ __forceinline__ void ldsWrite(char* base, unsigned byteOff, double v)
 __device__ __forceinline__ void ldsMax(char* base, unsigned byteOff, double v) {
   __hip_atomic_fetch_max(reinterpret_cast<double*>(base + byteOff), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// exchange buffer: 8-byte agent-scope atomics on both sides (the offers are performed at the memory
+// side, the owner's loads and clears bypass this CU's L1), so a hand-over needs no fence
+__device__ __forceinline__ void xMax(char* base, unsigned byteOff, double v) {
+  __hip_atomic_fetch_max(reinterpret_cast<double*>(base + byteOff), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double xLoad(const char* base, unsigned byteOff) {
+  return __hip_atomic_load(reinterpret_cast<const double*>(base + byteOff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void xStore(char* base, unsigned byteOff, double v) {
+  __hip_atomic_store(reinterpret_cast<double*>(base + byteOff), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned wLoad(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // keep a register-resident entry opaque inside the column loop, so that nothing decoded from
 // it is hoisted out and kept live across iterations
@@ -121,30 +158,66 @@ constexpr double kFresh = __builtin_huge_val();   // "not evaluated in this colu
 #ifndef DNAS_NT_D
 #define DNAS_NT_D 1
 #endif
+// Cluster constants.  Exchange buffer of one cluster: XA.dc | XB.dc | XB.sc, kCells doubles each (XA: the
+// emit offers between columns, XB: the offers of the in-column fixpoint -- two sets, because a fast member
+// is already offering into the fixpoint while a slow one still reads its between-column cells), then the
+// two cells of the end-of-read reduction.  Sync block of one cluster (64 u32): [0] GE, [1] abort,
+// [2, 2+G) idle word per member, [40] placement census (OR of 1 << XCC id).
+constexpr int G_ = DNAS_G;
+constexpr unsigned kCells = (unsigned)DNAS_G * DNAS_GROWS * DNAS_T;
+constexpr unsigned kXStride = 3u * kCells + 8u;   // doubles per cluster
+constexpr bool rowG(int k) { return kRows[k].gIdx >= 0; }
+constexpr bool rowHasS(int k) { return kRows[k].gIdx >= 0 || kRows[k].sIdx >= 0; }
 
 extern "C" __global__ void __launch_bounds__(DNAS_T)
-viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntries][T]
-                   const unsigned* __restrict__ metaTab,                // [K][T]: mdl | ctx<<4 | flags
+viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kEntries][T]
+                   const unsigned* __restrict__ metaTab,                // [G][K][T]: mdl | ctx<<4 | flags
                    const unsigned char* __restrict__ bases, const unsigned long long* __restrict__ readOff,
                    const int* __restrict__ batchRead, const unsigned long long* __restrict__ slotOff,
                    double* __restrict__ arena, double* __restrict__ outLoglike,
-                   unsigned long long* __restrict__ roundsTotal) {
+                   unsigned long long* __restrict__ roundsTotal,
+                   double* __restrict__ xbuf, unsigned* __restrict__ syncWords, int nClusters, int nReads,
+                   unsigned long long timeoutTicks) {
   extern __shared__ double lds[];
   extern __shared__ unsigned ldsU[];
-  constexpr int T = DNAS_T, K = DNAS_K, D_ = DNAS_D, lanes = 2, NS = DNAS_NS;   // stored lanes: S, D
+  constexpr int T = DNAS_T, K = DNAS_K, D_ = DNAS_D, lanes = 2, NSm = DNAS_NS, NS = DNAS_NS * DNAS_G;   // stored lanes: S, D
   const int tid = threadIdx.x;
   char* const ldsB = reinterpret_cast<char*>(lds);
   const double* const subL = lds + (kTabBase / 8) + 4;
   // the vote words live in the same dynamic LDS block; a second extern array (same base) keeps
   // the accesses in the LDS address space (a volatile generic pointer would turn them into
   // flat_* operations that wait on every outstanding global store)
-  unsigned* const epochL = ldsU + 2 * ((kTabBase / 8) + 28 + DNAS_T / 64);   // termination words: epoch, idle[T/64]
+  unsigned* const epochL = ldsU + 2 * ((kTabBase / 8) + 28 + DNAS_T / 64);   // termination words: epoch, idle[T/64], done, ge, abort
   unsigned* const idleL = epochL + 1;
+  unsigned* const doneL = idleL + DNAS_T / 64;
+  unsigned* const geL = doneL + 1;
+  unsigned* const abortL = doneL + 2;
 
-  const int read = batchRead[blockIdx.x];
-  const unsigned char* seq = bases + readOff[read];
-  const int L = (int)(readOff[read + 1] - readOff[read]);
-  double* const lat = arena + slotOff[blockIdx.x];
+  // ---- who am I: tier A one work-group per read; tier C member `member` of cluster `cluster`, which
+  // walks the reads cluster, cluster + nClusters, ...  Blocks b and b + 8 land on the same XCD (observed
+  // dispatch order, speed only): the members of a cluster are 8 blocks apart.
+  int member = 0, rFirst = (int)blockIdx.x, rStep = 1, rEnd = (int)blockIdx.x + 1;
+  char* xB = nullptr;          // this cluster's exchange buffer (bytes)
+  unsigned* SY = nullptr;      // this cluster's sync block
+  if constexpr (G_ > 1) {
+    const int b = (int)blockIdx.x, q = b >> 3;
+    member = q % G_;
+    const int cluster = (q / G_) * 8 + (b & 7);
+    if (cluster >= nClusters) return;
+    rFirst = cluster; rStep = nClusters; rEnd = nReads;
+    xB = reinterpret_cast<char*>(xbuf + (size_t)cluster * kXStride);
+    SY = syncWords + (size_t)cluster * 64;
+    entTab += (size_t)member * kEntries * T;
+    metaTab += (size_t)member * K * T;
+    if (tid == 0) {
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      __hip_atomic_fetch_or(&SY[40], 1u << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  constexpr unsigned kXA = 0u, kXBd = kCells * 8u, kXBs = 2u * kCells * 8u, kXRed = 3u * kCells * 8u;
+  // own exchange cells of G row k: cell (member*GROWS + gIdx)*T + tid
+#define X_OWN(k) ((unsigned)(((unsigned)member * DNAS_GROWS + (unsigned)kRows[k].gIdx) * T + (unsigned)tid) * 8u)
 
   unsigned E[kEntries];
   static_for<0, kEntries>([&](auto m) { E[m.value] = entTab[(size_t)m.value * T + tid]; });
@@ -164,7 +237,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
   };
   // own accumulators: byte addresses
   const unsigned ownB = (unsigned)tid * 8u;
-#define DC_OWN(k) (ownB + (unsigned)kDCBase + (unsigned)(k) * T * 8u)
+#define DC_OWN(k) (ownB + (unsigned)kDCBase + (unsigned)((k) - DNAS_GROWS) * T * 8u)
 #define SC_OWN(k) (ownB + (unsigned)kRows[k].sIdx * T * 8u)
 
   double S[K], Dv[K];   // after phase C, Dv[k] carries the T1 hand-over to the next column's phase A
@@ -181,14 +254,14 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
   if (tid < 4) lds[kTabBase / 8 + tid] = a.score[tid];
   if (tid < 16) lds[kTabBase / 8 + 4 + tid] = a.sub[tid];
   if (tid < 8) lds[kTabBase / 8 + 20 + tid] = a.len[tid];
-  if (tid < 1 + DNAS_T / 64) epochL[tid] = 0;
+  if (tid < 4 + DNAS_T / 64) epochL[tid] = 0;
   __syncthreads();
 
   // The S and D lanes of column p leave for HBM from the registers, 16 bytes per lane (rows 2m and
   // 2m+1 of a thread are lattice neighbours).
 #define STORE_LANE(p, lane, REG)                                                                 \
   {                                                                                              \
-    double* const colp = lat + ((size_t)(p) * lanes + (lane)) * NS;                              \
+    double* const colp = latM + ((size_t)(p) * lanes + (lane)) * NS;                             \
     static_for<0, K / 2>([&](auto mc) {                                                          \
       constexpr int m2 = mc.value;                                                               \
       if (pairValid & (1u << m2)) {                                                              \
@@ -206,9 +279,52 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
     if ((META(2 * mc.value) | META(2 * mc.value + 1)) & 0x20000000u) pairValid |= 1u << mc.value;
   });
 
-  for (int pos = 0; pos <= L; ++pos) {
-    double* const col = lat + (size_t)pos * lanes * NS;
+  // ---- cluster synchronisation (tier C).  GE only grows.  geBase = its value when the cluster last agreed
+  // (every member holds the same number); a column starts with one bump per member, which is the
+  // barrier behind the between-column offers AND what makes the idle words of the previous column stale.
+  unsigned geBase = 0, colSeq = 0;
+  bool aborted = false;
+  unsigned long long tStart = 0ull;   // watchdog: a column that takes longer than timeoutTicks (100 MHz) aborts the launch
+  // all offers of this work-group into the exchange buffer have completed -> bump -> wait for every member
+  auto clusterBarrier = [&]() {
+    if constexpr (G_ > 1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's exchange atomics and clears are done
+      __syncthreads();
+      geBase += (unsigned)G_;
+      if (tid < 64) {
+        if (tid == 0) __hip_atomic_fetch_add(&SY[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (unsigned spin = 0;; ++spin) {
+          const unsigned v = tid < 2 ? wLoad(&SY[tid]) : 0u;
+          const unsigned ge = __shfl(v, 0, 64), ab = __shfl(v, 1, 64);
+          if ((int)(ge - geBase) >= 0) break;
+          if (ab || ((spin & 255u) == 255u && __builtin_amdgcn_s_memrealtime() - tStart > timeoutTicks)) {
+            if (tid == 0) { __hip_atomic_store(&SY[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *abortL = 1u; }
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+        }
+      }
+      __syncthreads();
+      aborted = *abortL != 0u;
+    }
+  };
+
+  for (int r = rFirst; r < rEnd && !aborted; r += rStep) {
+  const int read = batchRead[r];
+  const unsigned char* seq = bases + readOff[read];
+  const int L = (int)(readOff[read + 1] - readOff[read]);
+  double* const lat = arena + slotOff[r];
+  double* const latM = lat + (size_t)member * NSm;   // this member's slots of a column
+  const unsigned redOff = kXRed + (unsigned)(((r - rFirst) / rStep) & 1) * 8u;
+  if constexpr (G_ > 1) {
+    if (member == 0 && tid == 0) xStore(xB, redOff, kNegInf);   // this read's reduction cell (last used two reads ago)
+  }
+
+  for (int pos = 0; pos <= L && !aborted; ++pos) {
+    double* const col = latM + (size_t)pos * lanes * NS;
     const int x = pos > 0 ? seq[pos - 1] : 0;
+    ++colSeq;
+    if constexpr (G_ > 1) tStart = __builtin_amdgcn_s_memrealtime();
 #ifdef DNAS_STAMP
     t0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -226,18 +342,39 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
           static_for<0, rowOut(k)>([&](auto ec) {
             const unsigned en = opaque(E[o + ec.value]);
             if constexpr (kRows[k].kind == 2) return;             // no emit edge in this row
+            if constexpr (kRows[k].gOut != 0) {
+              if (kRows[k].gOut == 1 ? ENT_VALID(en) : ENT_GLOBAL(en)) {
+                if (kRows[k].kind == 1 || !ENT_GNULL(en))
+                  xMax(xB, kXA + ENT_GCELL(en), (withScoreRow(kc, S[k], en) + a.noGap) + ldsRead(ldsB, subRow + ENT_GBASE32(en)));
+                return;
+              }
+              if constexpr (kRows[k].gOut == 1) return;
+            }
             const bool emit = kRows[k].kind == 1 ? (kRows[k].full != 0 || ENT_VALID(en)) : ENT_EMIT(en);
             if (emit) ldsMax(ldsB, ENT_DC(en), (withScoreRow(kc, S[k], en) + a.noGap) + ldsRead(ldsB, subRow + ENT_BASE32(en)));
           });
         }
       });
-      __syncthreads();   // every offer of the previous column has landed
-      STAMP(tA)
+    }
+    if constexpr (G_ > 1) {
+      clusterBarrier();            // every member's offers of the previous column have landed
+      if (aborted) break;
+    } else if (pos > 0) {
+      __syncthreads();             // every offer of the previous column has landed
+    }
+    STAMP(tA)
+    if (pos > 0) {
       static_for<0, K>([&](auto kc) {
         constexpr int k = kc.value;
         if constexpr (rowLive(k)) {
-          S[k] = dmax(ldsRead(ldsB, DC_OWN(k)), Dv[k]);   // Dv: T1(pos-1) + sub[ctx1][x_pos], left there by phase C
-          ldsWrite(ldsB, DC_OWN(k), kNegInf);
+          // Dv: T1(pos-1) + sub[ctx1][x_pos], left there by phase C
+          if constexpr (rowG(k)) {
+            S[k] = dmax(xLoad(xB, kXA + X_OWN(k)), Dv[k]);
+            xStore(xB, kXA + X_OWN(k), kNegInf);      // nobody offers here again before the next column's barrier
+          } else {
+            S[k] = dmax(ldsRead(ldsB, DC_OWN(k)), Dv[k]);
+            ldsWrite(ldsB, DC_OWN(k), kNegInf);
+          }
           Dv[k] = kFresh;
         }
       });
@@ -248,7 +385,6 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
         S[k] = ((mt & 0x20000000u) && (a.local || (mt & 0x80000000u))) ? 0.0 : kNegInf;   // viterbi.cpp:75-79
         Dv[k] = rowLive(k) ? kFresh : kNegInf;   // an empty row stays (-inf, -inf) for the whole read
       });
-      STAMP(tA)
     }
     __syncthreads();   // every DC is cleared before the first offer of the fixpoint
     STAMP(tP)
@@ -264,27 +400,41 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
     // every cell is consistent with its inputs, i.e. the fixpoint.  A row's accumulators are
     // read when its turn comes, so a value crosses every forward edge (source row < destination
     // row) within one sweep -- the plan lays the machine's chains out along ascending rows.
+    //
+    // Cluster: the same one level up.  GE is bumped by a wave after its exchange offers have completed
+    // (s_waitcnt vmcnt(0) in between, and again before the wave may call itself idle, so that its own bump
+    // has landed).  Wave 0 reads GE in every sweep and turns a change into a bump of the work-group's
+    // epoch: every wave then sweeps once more, i.e. reads its exchange cells AFTER that value of GE was
+    // seen.  A work-group whose waves are all idle, and whose wave 0 still reads the GE it last imported,
+    // writes GE+1 into its idle word; when every member's word says GE+1 and GE is still the same,
+    // every offer ever made was read by its owner in a sweep that grew nothing: the fixpoint.
     {
       constexpr int NW = DNAS_T / 64;
       const int wv = tid >> 6, ln = tid & 63;
+      unsigned geSeen = geBase;
       for (;;) {
         asm volatile("" ::: "memory");   // other waves write LDS between sweeps: reload everything
         const unsigned e0 = __hip_atomic_load(epochL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (ln == 0) __hip_atomic_store(&idleL[wv], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        int changed = 0;
+        int changed = 0, sentX = 0;
+        unsigned geNow = geSeen;
+        if constexpr (G_ > 1) { if (wv == 0) geNow = wLoad(&SY[0]); }
         static_for<0, K>([&](auto kc) {
           constexpr int k = kc.value, o = rowOffset(k);
           if constexpr (!rowLive(k)) return;
           // D is exactly what the in-edges have offered; a row with no S cells can only move when D
           // moved.  The first sweep of a column finds Dv == kFresh (no D cell is ever +inf) and offers
           // the starting values.
-          const double d = ldsRead(ldsB, DC_OWN(k));
-          double s = S[k];
-          bool grew = d != Dv[k];
-          if constexpr (kRows[k].sIdx >= 0) {
-            s = dmax(s, ldsRead(ldsB, SC_OWN(k)));
-            grew = grew || s != S[k];
+          double d, s = S[k];
+          if constexpr (rowG(k)) {
+            d = xLoad(xB, kXBd + X_OWN(k));
+            s = dmax(s, xLoad(xB, kXBs + X_OWN(k)));
+          } else {
+            d = ldsRead(ldsB, DC_OWN(k));
+            if constexpr (kRows[k].sIdx >= 0) s = dmax(s, ldsRead(ldsB, SC_OWN(k)));
           }
+          bool grew = d != Dv[k];
+          if constexpr (rowHasS(k)) grew = grew || s != S[k];
           if (grew) {
             changed = 1;
             s = dmax(s, d + a.delEnd);                                 // viterbi.cpp:114-115
@@ -294,39 +444,112 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
             static_for<0, rowOut(k)>([&](auto ec) {
               const unsigned en = opaque(E[o + ec.value]);
               if (kRows[k].full != 0 || ENT_VALID(en)) {
-                if constexpr (kRows[k].kind == 1) {
-                  ldsMax(ldsB, ENT_DC(en), withScoreRow(kc, xv, en));
-                } else if constexpr (kRows[k].kind == 2) {            // viterbi.cpp:137-151
-                  ldsMax(ldsB, ENT_DC(en), withScoreRow(kc, d, en));
-                  ldsMax(ldsB, ENT_SC(en), withScoreRow(kc, s, en));
-                } else if (ENT_EMIT(en)) {
-                  ldsMax(ldsB, ENT_DC(en), withScoreRow(kc, xv, en));
-                } else {
-                  ldsMax(ldsB, ENT_DC(en), withScoreRow(kc, d, en));
-                  ldsMax(ldsB, ENT_SC(en), withScoreRow(kc, s, en));
+                if constexpr (kRows[k].gOut != 0) {
+                  if (kRows[k].gOut == 1 || ENT_GLOBAL(en)) {
+                    sentX = 1;
+                    if (kRows[k].kind == 1 || (kRows[k].kind != 2 && !ENT_GNULL(en))) {
+                      xMax(xB, kXBd + ENT_GCELL(en), withScoreRow(kc, xv, en));
+                    } else {                                           // viterbi.cpp:137-151
+                      xMax(xB, kXBd + ENT_GCELL(en), withScoreRow(kc, d, en));
+                      xMax(xB, kXBs + ENT_GCELL(en), withScoreRow(kc, s, en));
+                    }
+                    return;
+                  }
+                }
+                if constexpr (kRows[k].gOut != 1) {
+                  if constexpr (kRows[k].kind == 1) {
+                    ldsMax(ldsB, ENT_DC(en), withScoreRow(kc, xv, en));
+                  } else if constexpr (kRows[k].kind == 2) {            // viterbi.cpp:137-151
+                    ldsMax(ldsB, ENT_DC(en), withScoreRow(kc, d, en));
+                    ldsMax(ldsB, ENT_SC(en), withScoreRow(kc, s, en));
+                  } else if (ENT_EMIT(en)) {
+                    ldsMax(ldsB, ENT_DC(en), withScoreRow(kc, xv, en));
+                  } else {
+                    ldsMax(ldsB, ENT_DC(en), withScoreRow(kc, d, en));
+                    ldsMax(ldsB, ENT_SC(en), withScoreRow(kc, s, en));
+                  }
                 }
               }
             });
           }
         });
         ++rounds;
+        if constexpr (G_ > 1) {
+          if (__any(sentX)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the exchange offers are performed ...
+            if (ln == 0) __hip_atomic_fetch_add(&SY[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before GE says so
+          }
+          if (wv == 0 && geNow != geSeen) { geSeen = geNow; changed = 1; }   // import: everybody sweeps once more
+        }
         if (__any(changed)) {
           // the offers above precede the bump (LDS operations of one wave execute in order)
           if (ln == 0) __hip_atomic_fetch_add(epochL, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
           continue;
         }
         if (__hip_atomic_load(epochL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != e0) continue;
+        if constexpr (G_ > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's bumps of GE have landed
         if (ln == 0) __hip_atomic_store(&idleL[wv], e0 + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         bool done = false;
         for (;;) {   // every wave reaches this exit: once all are idle nobody sweeps, so nobody bumps the epoch
           const unsigned v = ln < NW ? __hip_atomic_load(&idleL[ln], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : e0 + 1u;
-          if (__all(v == e0 + 1u)) { done = true; break; }
+          if (__all(v == e0 + 1u)) {
+            if constexpr (G_ == 1) { done = true; break; }
+            // the work-group is quiet; wave 0 asks the cluster, the others wait for its verdict
+            if (wv != 0) {
+              for (;;) {
+                if (__hip_atomic_load(doneL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == colSeq) { done = true; break; }
+                if (__hip_atomic_load(epochL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != e0) break;
+                __builtin_amdgcn_s_sleep(4);
+              }
+              break;
+            }
+            bool declared = false;
+            for (unsigned spin = 0;; ++spin) {
+              const unsigned w = ln < 2 + G_ ? wLoad(&SY[ln]) : 0u;
+              const unsigned ge = __shfl(w, 0, 64), ab = __shfl(w, 1, 64);
+              if (ab || ((spin & 255u) == 255u && __builtin_amdgcn_s_memrealtime() - tStart > timeoutTicks)) {
+                if (ln == 0) {
+                  __hip_atomic_store(&SY[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  *abortL = 1u;
+                  __hip_atomic_store(doneL, colSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                done = true;
+                break;
+              }
+              if (ge != geSeen) {          // somebody offered since: import and sweep again
+                geSeen = ge;
+                if (ln == 0) __hip_atomic_fetch_add(epochL, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                break;
+              }
+              if (!declared) {
+                if (ln == 0) __hip_atomic_store(&SY[2 + member], ge + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                declared = true;
+              } else if (__all(ln < 2 || ln >= 2 + G_ || w == ge + 1u)) {
+                // every member idle at ge: the verdict stands if GE has not moved since those words were read
+                if (wLoad(&SY[0]) == ge) {
+                  if (ln == 0) {
+                    *geL = ge;
+                    __hip_atomic_store(doneL, colSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                  }
+                  done = true;
+                  break;
+                }
+              }
+              __builtin_amdgcn_s_sleep(2);
+            }
+            break;
+          }
           if (__hip_atomic_load(epochL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != e0) break;   // someone grew a cell: sweep again
           __builtin_amdgcn_s_sleep(DNAS_SLEEP);
         }
         if (done) break;
       }
       __syncthreads();   // all waves are out of the sweeps before phase C clears the accumulators
+      if constexpr (G_ > 1) {
+        aborted = *abortL != 0u;
+        geBase = *geL;
+        if (aborted) break;
+      }
     }
     STAMP(tB)
 
@@ -378,8 +601,13 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
           if constexpr (!rowLive(k)) { Dv[k] = kNegInf; return; }
           const double s = S[k];
           const int mdl = (int)(metaG[k - k0] & 15u);
-          ldsWrite(ldsB, DC_OWN(k), kNegInf);
-          if constexpr (kRows[k].sIdx >= 0) ldsWrite(ldsB, SC_OWN(k), kNegInf);
+          if constexpr (rowG(k)) {
+            xStore(xB, kXBd + X_OWN(k), kNegInf);
+            xStore(xB, kXBs + X_OWN(k), kNegInf);
+          } else {
+            ldsWrite(ldsB, DC_OWN(k), kNegInf);
+            if constexpr (kRows[k].sIdx >= 0) ldsWrite(ldsB, SC_OWN(k), kNegInf);
+          }
           // T1(pos): chain from the deepest element (i = D-1) to i = 0.  Nearly every state has a
           // full context (mdl == D) and nearly every column a full history: that case is straight
           // line code, chosen per wave.
@@ -423,6 +651,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
     __syncthreads();   // every accumulator is -inf again
     STAMP(tC)
   }
+  if (aborted) break;
 #ifdef DNAS_STAMP
   if (tid == 0 && blockIdx.x == 0) { roundsTotal[1] = tA; roundsTotal[2] = tP; roundsTotal[3] = tB; roundsTotal[4] = tC; roundsTotal[5] = (unsigned long long)rounds; }
 #endif
@@ -430,7 +659,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
   // ---- loglike (viterbi.h:102); local mode overwrites the end state with the column max
   // (viterbi.cpp:171-173).  bit30 of meta marks the reference's last state.
   double* const red = lds + (kTabBase / 8) + 28;
-  double* const lastS = lat + (size_t)L * lanes * NS;
+  double* const lastS = latM + (size_t)L * lanes * NS;
   double best = kNegInf;
   static_for<0, K>([&](auto kc) {
     constexpr int k = kc.value;
@@ -442,21 +671,33 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [kEntr
   __syncthreads();
   if (tid == 0) {
     for (int w = 1; w < T / 64; ++w) best = dmax(best, red[w]);
-    red[0] = best;
-    outLoglike[read] = best;
-    atomicAdd(roundsTotal, (unsigned long long)rounds);
+    if constexpr (G_ > 1) xMax(xB, redOff, best);
+    else { red[0] = best; outLoglike[read] = best; }
+  }
+  if constexpr (G_ > 1) {
+    clusterBarrier();          // every member's best has landed (and the last column's accumulators are clear)
+    if (aborted) break;
+    if (tid == 0) red[0] = xLoad(xB, redOff);
   }
   __syncthreads();
-  if (a.local) {
+  {
+    bool owner = false;
     static_for<0, K>([&](auto kc) {
       constexpr int k = kc.value;
       if (META(k) & 0x40000000u) {
-        // the reference overwrites S(N-1, L) AFTER the duplication lanes of the last column were formed
-        // from it (viterbi.cpp:161-173); those lanes are not stored here, so the value they came from is
-        // kept in the spare cell behind the read's lattice for whoever rebuilds them (expand_lattice_kernel)
-        lat[(size_t)(L + 1) * lanes * NS] = S[k];
-        lastS[(k >> 1) * 2 * T + 2 * tid + (k & 1)] = red[0];
+        owner = true;
+        if (a.local) {
+          // the reference overwrites S(N-1, L) AFTER the duplication lanes of the last column were formed
+          // from it (viterbi.cpp:161-173); those lanes are not stored here, so the value they came from is
+          // kept in the spare cell behind the read's lattice for whoever rebuilds them (expand_lattice_kernel)
+          lat[(size_t)(L + 1) * lanes * NS] = S[k];
+          lastS[(k >> 1) * 2 * T + 2 * tid + (k & 1)] = red[0];
+        }
       }
     });
+    if constexpr (G_ > 1) { if (owner) outLoglike[read] = red[0]; }
   }
+  __syncthreads();             // red[] is free again
+  }   // reads of this cluster
+  if (tid == 0) atomicAdd(roundsTotal, (unsigned long long)rounds);
 }

@@ -94,6 +94,7 @@ def lib():
         "dnas_flat_view": (P(FlatModelC), [vp]),
         "dnas_flat_free": (None, [vp]),
         "dnas_model_create": (ctypes.c_int, [P(FlatModelC), ctypes.c_int, sz, P(vp)]),
+        "dnas_model_create_ex": (ctypes.c_int, [P(FlatModelC), ctypes.c_int, sz, cp, P(vp)]),
         "dnas_model_destroy": (None, [vp]),
         "dnas_viterbi_batch": (ctypes.c_int, [vp, i64, vp, vp, vp, vp, vp, vp, vp]),
         "dnas_viterbi_batch_device": (ctypes.c_int, [vp, i64, vp, vp, vp, vp, vp, vp, vp]),
@@ -103,6 +104,9 @@ def lib():
         "dnas_tiera_plan_tables": (ctypes.c_int, [P(FlatModelC), vp, vp, ctypes.c_size_t, vp, vp, vp]),
         "dnas_model_debug_words": (ctypes.c_int, [vp, vp]),
         "dnas_tiera_precompile": (ctypes.c_int, [P(FlatModelC), ctypes.c_char_p, sz]),
+        "dnas_tierc_precompile": (ctypes.c_int, [P(FlatModelC), ctypes.c_int32, ctypes.c_char_p, sz]),
+        "dnas_tierc_plan": (ctypes.c_int, [P(FlatModelC), ctypes.c_int32, vp, vp, vp, sz, vp, vp, vp, vp]),
+        "dnas_model_cluster_census": (ctypes.c_int, [vp, vp, vp]),
         "dnas_model_last_stats": (ctypes.c_int, [vp, P(BatchStatsC)]),
         "dnas_model_read_lattice": (ctypes.c_int, [vp, i64, i64, vp]),
         "dnas_fwdback_estep": (ctypes.c_int, [P(MutatorParamsC), ctypes.c_int, i64] + [vp] * 8 + [ctypes.c_int, vp, vp, vp]),

@@ -124,6 +124,12 @@ void dnas_flat_free(dnas_flat *f);
 /* Upload the flattened model to GPU `device_id` and size the lattice arena.
  * arena_bytes = 0 picks a default (a fraction of free HBM). */
 int dnas_model_create(const dnas_flat_model *fm, int device_id, size_t arena_bytes, dnas_model **out);
+/* The same with options, "key=value,key=value" (NULL: none).  Keys: tier = A | B | C (force a fill kernel; failing
+ * to provide it is then an error), cluster = work-groups per read for tier C, max_clusters, max_slots (reads per
+ * fill launch), cluster_timeout_s (tier C watchdog per lattice column).  A key that is absent falls back to the
+ * environment variable DNAS_<KEY IN UPPER CASE>. */
+int dnas_model_create_ex(const dnas_flat_model *fm, int device_id, size_t arena_bytes, const char *options,
+                         dnas_model **out);
 void dnas_model_destroy(dnas_model *model);
 
 /*
@@ -157,6 +163,20 @@ int dnas_model_sync(dnas_model *model);
 const char *dnas_model_tier(const dnas_model *model);
 /* Specialise + compile the tier-A kernel for a machine ahead of time (no GPU needed). */
 int dnas_tiera_precompile(const dnas_flat_model *fm, char *note, size_t note_cap);
+
+/* Tier C: the same kernel run by a cluster of `members` work-groups per read (machines beyond one CU).
+ * dnas_tierc_precompile compiles it ahead of time (members = 0: the smallest cluster that fits; no GPU needed).
+ * dnas_tierc_plan is an analysis / test aid: the tables exactly as the kernel receives them.  info[8] =
+ * {members, rows, threads, entries per member, S stripes, exchange rows, 0, 0}; the other outputs may be NULL:
+ * row_shapes[rows][7] = {entries, S stripe, kind, class, full, exchange row ordinal, entries into the exchange
+ * buffer: 0 none / 1 all / 2 mixed}, entries[members][entries][threads], meta[members][rows][threads],
+ * member_of[n_states], lds_index[n_states] = row*threads + lane inside the member, lattice_slot[n_states].
+ * members = 1 describes the tier-A plan.  dnas_model_cluster_census: clusters that ran in the last call and how
+ * many of them had members on more than one XCD (placement is a speed matter only). */
+int dnas_tierc_precompile(const dnas_flat_model *fm, int32_t members, char *note, size_t note_cap);
+int dnas_tierc_plan(const dnas_flat_model *fm, int32_t members, int32_t *info, int32_t *row_shapes, uint32_t *entries,
+                    size_t entries_cap, uint32_t *meta, int32_t *member_of, int32_t *lds_index, int32_t *lattice_slot);
+int dnas_model_cluster_census(dnas_model *model, int32_t *clusters, int32_t *split);
 
 /* Analysis / test aid: where tier A puts each state (lds_index = row*threads + lane; lattice_slot = its
  * position inside a lattice row).  No GPU needed.  DNAS_E_UNSUPPORTED when the machine does not fit tier A. */

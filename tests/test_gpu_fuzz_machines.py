@@ -1,5 +1,5 @@
 """Random machines (tests/random_machines.py) through the real HIP path: decoded strings, fp64
-log-likelihoods and every lattice cell bit-identical to the oracle, under both fill kernels."""
+log-likelihoods and every lattice cell bit-identical to the oracle, under all three fill tiers."""
 import numpy as np
 import pytest
 
@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("seed,n_states,global_", [(1, 40, True), (2, 90, False), (3, 150, True), (6, 2300, True), (7, 5000, False)])
-@pytest.mark.parametrize("tier", ["A", "B"])
+@pytest.mark.parametrize("tier", ["A", "B", "C"])
 def test_random_machine_gpu_matches_oracle(oracle_mod, seed, n_states, global_, tier, monkeypatch):
     import dnastore_amd as da
     O = oracle_mod
@@ -17,7 +17,9 @@ def test_random_machine_gpu_matches_oracle(oracle_mod, seed, n_states, global_, 
         monkeypatch.setenv("DNAS_TIER", "B")
     text = random_machine(seed, n_states)
     flags = dict(global_=global_, sub=.02, dup=.01, del_open=.02, del_ext=.1)
-    dec = da.ViterbiDecoder(da.Machine.fromJSON(text), da.MutatorParams.fromFlags(**flags))
+    # tier C: the same machine cut over a cluster of 2 or 3 work-groups
+    options = "tier=C,cluster=%d" % (2 + seed % 2) if tier == "C" else None
+    dec = da.ViterbiDecoder(da.Machine.fromJSON(text), da.MutatorParams.fromFlags(**flags), options=options)
     assert dec.tier.startswith("tier " + tier)
     orc = O.ViterbiOracle(O.Machine.from_json(text), O.MutatorParams.from_cli(**flags))
     reads = [random_read(100 * seed + r, text, max_len=30) for r in range(4)]

@@ -11,7 +11,67 @@ import pytest
 NEG = -np.inf
 
 
-def _emulate(fm, seq, local):
+def _decode_plan(fm, members):
+    """Per-state out-edge lists [(dst, class, base, is_null)] and the has-S flag of every state, decoded from the
+    plan tables alone (members = 1: tier A; >= 2: a tier-C cluster)."""
+    a = fm.arrays()
+    N = a["n_states"]
+    pl = fm.cluster_plan(members)
+    G, K, T, shapes, ent = pl["G"], pl["K"], pl["T"], pl["shapes"], pl["entries"]
+    n_s, n_g = pl["n_s_rows"], pl["n_g_rows"]
+    member_of, lds_idx = pl["member_of"], pl["lds_index"]
+    dc_base = n_s * T * 8 + 64
+    row_off = np.concatenate([[0], np.cumsum(np.maximum(shapes[:, 0], 0))])
+    state_at = np.full((G, K * T), -1, dtype=np.int64)
+    state_at[member_of, lds_idx] = np.arange(N)
+    assert (state_at >= 0).sum() == N, "two states share a place"
+    out = [[] for _ in range(N)]
+    for j in range(N):
+        g = int(member_of[j])
+        k, t = divmod(int(lds_idx[j]), T)
+        assert shapes[k, 0] >= 0, "state placed in a row the plan marks empty"
+        kind, cls_common, g_out = shapes[k, 2], shapes[k, 3], shapes[k, 6]
+        for e in range(int(shapes[k, 0])):
+            en = int(ent[g, row_off[k] + e, t])
+            if en == 0:
+                assert not shapes[k, 4], "empty entry in a row the plan calls full"
+                continue
+            cls = en & 3
+            assert cls_common < 0 or cls == cls_common
+            if en & 4:                                            # destination in the exchange buffer
+                assert g_out in (1, 2)
+                cell = (en >> 3) & 0xfffff
+                dg, rest = divmod(cell, n_g * T)
+                drow, dlane = divmod(rest, T)
+                assert shapes[drow, 5] == drow, "exchange cell outside the exchange rows"
+                dst = int(state_at[dg, drow * T + dlane])
+                is_null = bool(en & 0x800000)
+                base = (en >> 24) & 3
+            else:
+                assert g_out in (0, 2)
+                dst_idx = ((en & 0x3fff8) - dc_base) // 8 + n_g * T   # the exchange rows keep no cells in LDS
+                dst = int(state_at[g, dst_idx])
+                drow = dst_idx // T
+                assert shapes[drow, 5] < 0, "LDS entry into an exchange row"
+                is_null = en < 0xffe00000
+                base = (en >> 19) & 3
+                if is_null:
+                    sc_idx = en >> 19
+                    assert shapes[drow, 1] >= 0 and sc_idx == shapes[drow, 1] * T + dst_idx % T, "S cell of a null edge is not the destination's"
+            assert dst >= 0, "entry points at an empty slot"
+            assert kind == 0 or kind == (2 if is_null else 1)
+            out[j].append((dst, cls, base, is_null))
+    rows = lds_idx // T
+    has_s = (shapes[rows, 1] >= 0) | (shapes[rows, 5] >= 0)
+    # an edge between two members must go through the exchange buffer (the destination sits in an exchange row)
+    for j in range(N):
+        for dst, _, _, _ in out[j]:
+            if member_of[dst] != member_of[j]:
+                assert shapes[rows[dst], 5] >= 0
+    return out, has_s
+
+
+def _emulate(fm, seq, local, members=1):
     """S and D lanes [L+1][N] computed from the plan tables alone (+ the score scalars of the flat model)."""
     a = fm.arrays()
     N, D = a["n_states"], a["max_dup_len"]
@@ -19,39 +79,19 @@ def _emulate(fm, seq, local):
     del_open, tan_dup, no_gap, del_extend, del_end = sc[:5]
     sub = sc[5:21].reshape(4, 4)
     length = sc[21:]
-    shapes, ent, meta, n_s = fm.plan_tables()
-    lds_idx, _, T, K = fm.plan_slots()
-    dc_base = n_s * T * 8 + 64
     # distinct edge scores in the plan's class order: 0.0 first, then by first appearance over destinations
     scores = [0.0]
     for j in range(N):
         for v in list(a["ein_score"][a["ein_ptr"][j]:a["ein_ptr"][j + 1]]) + list(a["nin_score"][a["nin_ptr"][j]:a["nin_ptr"][j + 1]]):
             if v not in scores:
                 scores.append(v)
-    row_off = np.concatenate([[0], np.cumsum(np.maximum(shapes[:, 0], 0))])
-    state_at = np.full(K * T, -1, dtype=np.int64)
-    state_at[lds_idx] = np.arange(N)
-    # decode the entries into per-state out-edge lists
-    out = [[] for _ in range(N)]
-    for j in range(N):
-        k, t = divmod(int(lds_idx[j]), T)
-        assert shapes[k, 0] >= 0, "state placed in a row the plan marks empty"
-        for e in range(int(shapes[k, 0])):
-            en = int(ent[row_off[k] + e, t])
-            if en == 0:
-                continue
-            dst_idx = ((en & 0x3fff8) - dc_base) // 8
-            dst = int(state_at[dst_idx])
-            assert dst >= 0, "entry points at an empty slot"
-            cls = en & 3
-            if en >= 0xffe00000:
-                out[j].append((dst, cls, (en >> 19) & 3, None))
-            else:
-                sc_idx = en >> 19
-                drow = dst_idx // T
-                assert shapes[drow, 1] >= 0 and sc_idx == shapes[drow, 1] * T + dst_idx % T, "S cell of a null edge is not the destination's"
-                out[j].append((dst, cls, 0, sc_idx))
-    has_s = np.array([shapes[int(lds_idx[j]) // T, 1] >= 0 for j in range(N)])
+    out, has_s = _decode_plan(fm, members)
+    # the decoded edges are exactly the machine's usable edges
+    want = sorted([(int(a["ein_src"][e]), j, int(a["ein_base"][e]), False) for j in range(N) for e in range(a["ein_ptr"][j], a["ein_ptr"][j + 1])] +
+                  [(int(a["nin_src"][e]), j, 0, True) for j in range(N) for e in range(a["nin_ptr"][j], a["nin_ptr"][j + 1])])
+    got = sorted((j, dst, 0 if is_null else base, is_null) for j in range(N) for dst, _, base, is_null in out[j])
+    assert got == want
+    out = [[(dst, cls, base, (0 if is_null else None)) for dst, cls, base, is_null in lst] for lst in out]
     mdl = a["mdl"].astype(int)
     ctx = a["ctx"].astype(int)
     L = len(seq)
@@ -122,9 +162,10 @@ def test_plan_tables_reproduce_the_oracle_lattice(oracle_mod, ref_data, mach, fa
     read = da.read_fastseqs(os.path.join(ref_data, fa))[0][1][:24]          # pure-Python loops: keep it short
     orc = O.ViterbiOracle(O.Machine.from_file(path), O.MutatorParams.from_cli(**flags))
     _, _, olat = orc.decode(read, want_lattice=True)                       # [L+1][N][lanes]
-    S_lat, D_lat = _emulate(fm, da.tokenize(read), local=not flags.get("global_", False))
-    assert np.array_equal(S_lat.view(np.uint64), np.ascontiguousarray(olat[:, :, 0]).view(np.uint64))
-    assert np.array_equal(D_lat.view(np.uint64), np.ascontiguousarray(olat[:, :, 1]).view(np.uint64))
+    for members in (1, 2, 3):      # tier A, and the same machine cut over a cluster of 2 and 3 work-groups (tier C)
+        S_lat, D_lat = _emulate(fm, da.tokenize(read), local=not flags.get("global_", False), members=members)
+        assert np.array_equal(S_lat.view(np.uint64), np.ascontiguousarray(olat[:, :, 0]).view(np.uint64))
+        assert np.array_equal(D_lat.view(np.uint64), np.ascontiguousarray(olat[:, :, 1]).view(np.uint64))
 
 
 def test_plan_row_program_invariants(ref_data):
