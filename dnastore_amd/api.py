@@ -166,22 +166,23 @@ class FlatModel:
         return shapes, ent, meta, ns.value
 
     def cluster_plan(self, members=0):
-        """Tier-C tables (members = 1: the tier-A plan): dict(G, K, T, n_entries, n_s_rows, n_g_rows, shapes int32[K][7],
-        entries uint32[G][n_entries][T], meta uint32[G][K][T], member_of, lds_index, lattice_slot)."""
+        """Tier-C tables (members = 1: the tier-A plan): dict(G, K, T, n_entries, n_s_rows, n_inbox_rows, shapes int32[K][6],
+        entries uint32[G][n_entries][T], meta uint32[G][K][T], member_of, lds_index, lattice_slot, fold uint32[G][n_inbox_rows][T])."""
         n = self.view.contents.n_states
         info = np.zeros(8, dtype=np.int32)
-        _l.check(_l.lib().dnas_tierc_plan(self.view, int(members), info.ctypes.data, None, None, 0, None, None, None, None))
+        _l.check(_l.lib().dnas_tierc_plan(self.view, int(members), info.ctypes.data, None, None, 0, None, None, None, None, None))
         G, K, T, ne = (int(v) for v in info[:4])
-        shapes = np.zeros((K, 7), dtype=np.int32)
+        shapes = np.zeros((K, 6), dtype=np.int32)
+        fold = np.zeros((G, max(int(info[5]), 1), T), dtype=np.uint32)
         ent = np.zeros((G, ne, T), dtype=np.uint32)
         meta = np.zeros((G, K, T), dtype=np.uint32)
         member_of = np.full(n, -1, dtype=np.int32)
         lds = np.full(n, -1, dtype=np.int32)
         lat = np.full(n, -1, dtype=np.int32)
         _l.check(_l.lib().dnas_tierc_plan(self.view, G, info.ctypes.data, shapes.ctypes.data, ent.ctypes.data, ent.size, meta.ctypes.data,
-                                          member_of.ctypes.data, lds.ctypes.data, lat.ctypes.data))
-        return dict(G=G, K=K, T=T, n_entries=ne, n_s_rows=int(info[4]), n_g_rows=int(info[5]), shapes=shapes, entries=ent, meta=meta,
-                    member_of=member_of, lds_index=lds, lattice_slot=lat)
+                                          member_of.ctypes.data, lds.ctypes.data, lat.ctypes.data, fold.ctypes.data))
+        return dict(G=G, K=K, T=T, n_entries=ne, n_s_rows=int(info[4]), n_inbox_rows=int(info[5]), shapes=shapes, entries=ent, meta=meta,
+                    member_of=member_of, lds_index=lds, lattice_slot=lat, fold=fold[:, :int(info[5])])
 
     def precompile_cluster(self, members=0):
         """JIT-specialise the cluster (tier C) fill kernel for this machine into the kernel cache (no GPU needed)."""

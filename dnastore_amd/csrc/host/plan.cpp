@@ -16,10 +16,9 @@ constexpr int kMaxEntries = 40;   // entry registers per thread the kernel can a
 constexpr int kWalk = 30;         // length of the walks the sweep estimate looks at
 
 struct Edge { int src, dst, sc, base, isNull; };
-// out-edges, has null in-edges (and keeps its accumulators in LDS), not plain (some out-edge is a null edge or carries a
-// score), score class of the out-edges (4: they differ, 7: no out-edge) -- in a row's caps: the mask of classes it
-// admits --, has an in-edge from another member of the cluster (its accumulators live in the exchange buffer)
-typedef std::array<int, 5> Type;
+// out-edges, has null in-edges, not plain (some out-edge is a null edge or carries a score), score class of the
+// out-edges (4: they differ, 7: no out-edge) -- in a row's caps: the mask of classes it admits
+typedef std::array<int, 4> Type;
 
 // Which member of the cluster owns which state.  The in-column recursion runs along the machine's chains, and every
 // edge between two members costs a trip through the exchange buffer (microseconds, against nanoseconds inside a CU):
@@ -119,53 +118,61 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G) {
     }
   }
 
-  // ---- which member of the cluster owns which state; which states are fed through the exchange buffer
+  // ---- which member of the cluster owns which state.  A state with an in-edge from another member gets a slot in
+  // its member's INBOX: cells of the cluster's exchange buffer that the other members offer into and that the
+  // member folds into the state's LDS accumulators, slot r*T + t by thread t.
   std::vector<int> part(N, 0);
   if (G > 1) part = partitionStates(N, edges, walk, G, (int)((long)K * T * 93 / 100));
-  std::vector<char> isG(N, 0);
+  // The slots of the states that another member reaches over a NULL edge come first: only they need an S cell in
+  // the inbox (null edges carry S as well as D, viterbi.cpp:137-151), and the kernel polls S cells for those rows only.
+  std::vector<int> inboxSlot(N, -1);
+  std::vector<int> inboxCount(G, 0), inboxSCount(G, 0);
+  std::vector<char> remoteNull(N, 0);
   long nCross = 0;
   for (const Edge& e : edges)
-    if (part[e.src] != part[e.dst]) isG[e.dst] = 1;
-  for (const Edge& e : edges) nCross += isG[e.dst];
+    if (part[e.src] != part[e.dst]) { ++nCross; if (e.isNull) remoteNull[e.dst] = 1; }
+  for (int pass = 0; pass < 2; ++pass)
+    for (const Edge& e : edges)
+      if (part[e.src] != part[e.dst] && inboxSlot[e.dst] < 0 && (pass == 1 || remoteNull[e.dst])) {
+        inboxSlot[e.dst] = inboxCount[part[e.dst]]++;
+        if (pass == 0) ++inboxSCount[part[e.dst]];
+      }
   p.crossEdges = edges.empty() ? 0. : (double)nCross / (double)edges.size();
   for (int j = 0; j < N; ++j)
     if (parent[j] >= 0 && part[parent[j]] != part[j]) parent[j] = -1;   // the dealing follows a member's own subtrees
   std::vector<std::vector<int>> walkOf(G);
   for (int j : walk) walkOf[part[j]].push_back(j);
-  int nGRows = 0;
-  if (G > 1) {
-    std::vector<int> gCount(G, 0);
-    for (int j = 0; j < N; ++j) gCount[part[j]] += isG[j];
-    for (int g = 0; g < G; ++g) nGRows = std::max(nGRows, (gCount[g] + T - 1) / T);
-    if (nGRows == 0) nGRows = 1;   // (a cluster whose members never talk: keep the kernel's shape)
-  }
-  p.nGRows = nGRows;
-  if ((long)G * nGRows * T > (1l << 20)) return no("more than 2^20 exchange cells");
+  int nInboxRows = 0;
+  for (int g = 0; g < G; ++g) nInboxRows = std::max(nInboxRows, (inboxCount[g] + T - 1) / T);
+  if (G > 1 && nInboxRows == 0) nInboxRows = 1;   // (a cluster whose members never talk: keep the kernel's shape)
+  int nInboxSRows = 0;
+  for (int g = 0; g < G; ++g) nInboxSRows = std::max(nInboxSRows, (inboxSCount[g] + T - 1) / T);
+  p.nGRows = nInboxRows;
+  p.nGSRows = nInboxSRows;
+  if ((long)G * nInboxRows * T > (1l << 20)) return no("more than 2^20 exchange cells");
+  if (nInboxRows > 6) return no("more than " + std::to_string(6 * T) + " states of a member are fed by other members");
 
   std::vector<Type> type(N);
-  int maxOut = 0, maxOutG = 0;
+  int maxOut = 0;
   std::vector<int> nNullDestOf(G, 0);
   for (int j = 0; j < N; ++j) {
     int hasS = 0;
     for (int e : inOf[j]) hasS |= edges[e].isNull;
-    if (isG[j]) hasS = 0;                 // a G row always carries an S cell (in the exchange buffer)
     int notPlain = 0;
     for (int e : outOf[j]) notPlain |= (edges[e].isNull || edges[e].sc != 0) ? 1 : 0;
     if (outOf[j].empty()) notPlain = 1;   // would leave an empty entry in an otherwise full plain row
     int cls = 7;
     for (int e : outOf[j]) cls = cls == 7 ? edges[e].sc : (cls == edges[e].sc ? cls : 4);
-    type[j] = Type{(int)outOf[j].size(), hasS, notPlain, cls, (int)isG[j]};
-    (isG[j] ? maxOutG : maxOut) = std::max(isG[j] ? maxOutG : maxOut, type[j][0]);
+    type[j] = Type{(int)outOf[j].size(), hasS, notPlain, cls};
+    maxOut = std::max(maxOut, type[j][0]);
     nNullDestOf[part[j]] += hasS;
   }
   int nNullDestMax = 0;
   for (int g = 0; g < G; ++g) nNullDestMax = std::max(nNullDestMax, nNullDestOf[g]);
   if (getenv("DNAS_PLAN_DEBUG") && G > 1) {
-    std::vector<int> gc(G, 0);
-    for (int j = 0; j < N; ++j) gc[part[j]] += isG[j];
     for (int g = 0; g < G; ++g)
-      fprintf(stderr, "plan member %d: %zu states, %d fed through the exchange buffer, %d with null in-edges in LDS\n", g, walkOf[g].size(), gc[g], nNullDestOf[g]);
-    fprintf(stderr, "plan: K %d exchange rows %d cross edges %.4f\n", K, nGRows, p.crossEdges);
+      fprintf(stderr, "plan member %d: %zu states, %d fed by other members, %d with null in-edges\n", g, walkOf[g].size(), inboxCount[g], nNullDestOf[g]);
+    fprintf(stderr, "plan: K %d inbox rows %d cross edges %.4f\n", K, nInboxRows, p.crossEdges);
   }
 
   // ---- which state goes to which row ------------------------------------------------------
@@ -184,8 +191,7 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G) {
   // largest number of backward edges on any walk of kWalk edges); the best one that fits the
   // registers and the LDS is kept.  DNAS_PLAN_DEBUG=1 prints the candidates, DNAS_PLAN_PICK=
   // "rows,S-rows,groups,ascending,plain,typedS" forces one (experiments).
-  // In a cluster the G rows come first: what another member offered is read at the start of a
-  // sweep and runs down the member's own rows within that sweep.  All members share the program.
+  // The members of a cluster share the program.
   std::map<Type, int> typeId;
   std::vector<int> typeOf(N);
   std::vector<Type> types;
@@ -199,12 +205,9 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G) {
     std::vector<unsigned> admits(types.size(), 0), own(types.size(), 0);
     for (size_t t = 0; t < types.size(); ++t)
       for (int k = 0; k < K; ++k)
-        if (types[t][0] <= caps[k][0] && types[t][1] <= caps[k][1] && types[t][2] <= caps[k][2] && ((caps[k][3] >> types[t][3]) & 1) &&
-            types[t][4] <= caps[k][4]) {
-          // (a state without an in-edge from another member may sit in an exchange row when nothing else is free: all its
-          //  in-edges then go through the exchange buffer)
+        if (types[t][0] <= caps[k][0] && types[t][1] <= caps[k][1] && types[t][2] <= caps[k][2] && ((caps[k][3] >> types[t][3]) & 1)) {
           admits[t] |= 1u << k;
-          if (types[t][4] == caps[k][4] && (types[t][1] == caps[k][1] || caps[k][4])) own[t] |= 1u << k;     // S rows and exchange rows are kept for the states that need them
+          if (types[t][1] == caps[k][1]) own[t] |= 1u << k;     // S rows are kept for the states that need them
         }
     rows->assign(N, -1);
     for (int g = 0; g < G; ++g) {
@@ -252,7 +255,7 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G) {
     return true;
   };
   auto score = [&](const std::vector<int>& rows, int* readsOut, int* backOut, int* entriesOut) -> double {
-    std::vector<Type> shape(K, Type{0, 0, 0, 0, 0});
+    std::vector<Type> shape(K, Type{0, 0, 0, 0});
     for (int j = 0; j < N; ++j)
       for (int q = 0; q < 3; ++q) shape[rows[j]][q] = std::max(shape[rows[j]][q], type[j][q]);
     std::vector<char> inUse(K, 0);
@@ -264,7 +267,7 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G) {
         int clsMask = 0;
         for (int j = 0; j < N; ++j) if (rows[j] == k && type[j][3] != 7) clsMask |= 1 << type[j][3];
         const bool oneClass = clsMask != 0 && (clsMask & (clsMask - 1)) == 0 && clsMask < 16;
-        reads += 1 + (k < nGRows ? 1 : shape[k][1]); entries += shape[k][0];
+        reads += 1 + shape[k][1]; entries += shape[k][0];
         offerCost += !shape[k][2] ? 0.25 * shape[k][0] : (oneClass ? 0.55 * shape[k][0] : shape[k][0]);
       }
     std::vector<int> f(N, 0), g(N);
@@ -284,8 +287,7 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G) {
     // cheaper).  Sweeps: the GPU needs about 8 + back/2 (measured on s16h74l4c4 layouts with back 12..17).
     return (0.5 * (double)reads + 1.5 * offerCost + 5.0) * (8.0 + 0.5 * (double)back);
   };
-  auto ldsNeed = [&](int nS) { return (size_t)(p.NSm - nGRows * T + nS * T + 8 + 28   // the exchange rows keep no cells in LDS
-                                                   + T / 64 + (T / 64 + 2) / 2 + 1 + 2) * sizeof(double); };
+  auto ldsNeed = [&](int nS) { return (size_t)(p.NSm + nS * T + 8 + 28 + T / 64 + (T / 64 + 2) / 2 + 1 + 2) * sizeof(double); };
 
   std::vector<int> rowOfState;
   std::vector<Type> bestCaps;
@@ -295,7 +297,6 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G) {
     {
       std::vector<std::vector<int>> oS(G), oP(G), oPP(G);
       for (int j = 0; j < N; ++j) {
-        if (isG[j]) continue;
         (type[j][1] ? oS : oP)[part[j]].push_back(type[j][0]);
         if (!type[j][1] && !type[j][2]) oPP[part[j]].push_back(type[j][0]);
       }
@@ -314,19 +315,16 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G) {
       merge(oPP, &outPlainP, true);
     }
     const int minS = (nNullDestMax + T - 1) / T;
-    const int KN = K - nGRows;                       // rows behind the G rows
-    if (KN < 1) return no("the exchange rows leave no room");
     double bestScore = -1;
     std::string why = "no row program fits";
     long biggest = 0;
     for (int g = 0; g < G; ++g) biggest = std::max(biggest, (long)walkOf[g].size());
     // K is even (lattice pairs); when the states fit K-1 rows the last one may stay empty and
     // costs nothing in a sweep -- tried both ways
-    for (int KU = K; KU >= std::max(1 + nGRows, K - 1); --KU)
-    for (int nS = minS; nS <= std::min(KU - nGRows, minS + 2); ++nS) {
+    for (int KU = K; KU >= std::max(1, K - 1); --KU)
+    for (int nS = minS; nS <= std::min(KU, minS + 2); ++nS) {
       if (ldsNeed(nS) > kTierALdsLimit) { why = "LDS working set " + std::to_string(ldsNeed(nS)) + " B exceeds one CU"; continue; }
       if ((long)KU * T < biggest) continue;
-      const int KUN = KU - nGRows;
       for (int groups = 1; groups <= std::max(1, std::min(3, nS)); ++groups) {
         for (int ascending = 0; ascending < 2; ++ascending)
         for (int plainRows = 0; plainRows < 2; ++plainRows)
@@ -335,15 +333,14 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G) {
           std::vector<int> isS(K, 0);
           for (int g = 0, left = nS; g < groups && nS > 0; ++g) {
             const int len = left / (groups - g);
-            const int at = g * KUN / groups;
-            for (int i = 0; i < len; ++i) isS[nGRows + std::min(KUN - 1, at + i)] = 1;
+            const int at = g * KU / groups;
+            for (int i = 0; i < len; ++i) isS[std::min(KU - 1, at + i)] = 1;
             left -= len;
           }
           if (std::accumulate(isS.begin(), isS.end(), 0) != nS) continue;   // runs collided
           std::vector<Type> caps(K);
           int seenS = 0, seenP = 0, nPlainRows = 0;
           for (int k = 0; k < K; ++k) {
-            if (k < nGRows) { caps[k] = Type{std::max(maxOutG, maxOut), 1, 1, 0xff, 1}; continue; }
             const std::vector<int>& sorted = isS[k] ? outS : outP;
             int& seen = isS[k] ? seenS : seenP;
             int cap = maxOut;
@@ -358,7 +355,7 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G) {
               const size_t have = (size_t)(std::upper_bound(outPlainP.begin(), outPlainP.end(), cap) - outPlainP.begin());
               if (have >= (size_t)(nPlainRows + 1) * T) { generic = 0; ++nPlainRows; }
             }
-            caps[k] = k < KU ? Type{cap, isS[k], generic, 0xff, 0} : Type{-1, -1, -1, 0, -1};   // closed rows admit nothing
+            caps[k] = k < KU ? Type{cap, isS[k], generic, 0xff} : Type{-1, -1, -1, 0};   // closed rows admit nothing
             ++seen;
           }
           if (typedS && nS > 0) {
@@ -444,7 +441,7 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G) {
             for (int k2 = 0; k2 < K; ++k2) {
               if (k2 == k || fill[(size_t)part[j] * K + k2] >= T) continue;
               const Type& c2 = bestCaps[k2];
-              if (type[j][0] > c2[0] || type[j][1] > c2[1] || type[j][2] > c2[2] || !((c2[3] >> type[j][3]) & 1) || type[j][4] != c2[4]) continue;
+              if (type[j][0] > c2[0] || type[j][1] > c2[1] || type[j][2] > c2[2] || !((c2[3] >> type[j][3]) & 1)) continue;
               if (type[j][0] > nOutNow[k2]) continue;      // would grow the row's entry registers
               const int have = common(k2);
               const int mine = attr == 0 ? clsOf(j) : kindOf(j);
@@ -524,11 +521,9 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G) {
   }
 
   // row shapes as used, S stripes
-  p.rows.assign(K, RowShape{0, -1, -1, -2, 0, -1, -1});   // kind / cls / gOut: -1 / -2 / -1 = no entry seen yet
-  std::vector<int> needS(K, 0), rowIsG(K, 0);
+  p.rows.assign(K, RowShape{0, -1, -1, -2, 0, -1});   // kind / cls / gOut: -1 / -2 / -1 = no entry seen yet
+  std::vector<int> needS(K, 0);
   long real = 0;
-  for (int j = 0; j < N; ++j) rowIsG[rowOfState[j]] |= isG[j];
-  for (int k = 0; k < nGRows; ++k) rowIsG[k] = 1;           // (also when no state sits there)
   for (int j = 0; j < N; ++j) {
     RowShape& r = p.rows[rowOfState[j]];
     r.nOut = std::max(r.nOut, type[j][0]);
@@ -536,22 +531,14 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G) {
       const int kind = edges[e].isNull ? 2 : 1;
       r.kind = r.kind < 0 ? kind : (r.kind == kind ? kind : 0);
       r.cls = r.cls == -2 ? edges[e].sc : (r.cls == edges[e].sc ? r.cls : -1);
-      const int go = rowIsG[rowOfState[edges[e].dst]] ? 1 : 0;
+      const int go = part[edges[e].dst] != part[j] ? 1 : 0;
       r.gOut = r.gOut < 0 ? go : (r.gOut == go ? go : 2);
-      if (!go && part[edges[e].dst] != part[j]) return no("internal: edge between members into an LDS row");
     }
     needS[rowOfState[j]] |= type[j][1];
     real += type[j][0];
   }
   p.nSRows = 0;
-  for (int k = 0; k < K; ++k) {
-    if (rowIsG[k]) {
-      if (k >= nGRows) return no("internal: exchange state outside the exchange rows");
-      p.rows[k].gIdx = k;
-    } else if (needS[k]) {
-      p.rows[k].sIdx = p.nSRows++;
-    }
-  }
+  for (int k = 0; k < K; ++k) if (needS[k]) p.rows[k].sIdx = p.nSRows++;
   std::vector<char> rowUsed(K, 0);
   for (int j = 0; j < N; ++j) rowUsed[rowOfState[j]] = 1;
   for (int k = 0; k < K; ++k) if (!rowUsed[k]) p.rows[k].nOut = -1;   // the kernel skips the row
@@ -596,12 +583,13 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G) {
       const Edge& e = edges[outOf[j][i]];
       const int drow = rowOfState[e.dst], dlane = laneOf[e.dst];
       unsigned ent;
-      if (rowIsG[drow]) {
-        // exchange cell (dst member, G row, lane):  [0:2) class | bit 2 | [3:23) cell | bit 23 null edge | [24:26) emitted base
-        const unsigned cell = (unsigned)((part[e.dst] * nGRows + p.rows[drow].gIdx) * T + dlane);
+      if (part[e.dst] != part[j]) {
+        // inbox cell of the destination:  [0:2) class | bit 2 | [3:23) cell | bit 23 null edge | [24:26) emitted base
+        const unsigned cell = (unsigned)(part[e.dst] * nInboxRows * T + inboxSlot[e.dst]);
+        if (e.isNull && p.rows[drow].sIdx < 0) return no("internal: null edge into a row without S cells");
         ent = (unsigned)e.sc | 4u | (cell << 3) | (e.isNull ? 1u << 23 : (unsigned)(e.base & 3) << 24);
       } else {
-        ent = (unsigned)e.sc | (dcBase + (unsigned)((drow - nGRows) * T + dlane) * 8u);
+        ent = (unsigned)e.sc | (dcBase + (unsigned)(drow * T + dlane) * 8u);
         if (e.isNull) {
           if (p.rows[drow].sIdx < 0) return no("internal: null edge into a row without S cells");
           ent |= (unsigned)(p.rows[drow].sIdx * T + dlane) << 19;
@@ -614,6 +602,18 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G) {
     }
   }
   p.sameWave = fwd ? (double)fwdSameWave / (double)fwd : 1.0;
+
+  // fold table: inbox slot r*T + t of a member -> LDS cells of the state behind it: DC byte address >> 3 | SC byte
+  // address >> 3 << 16 (0xffff: the state has no S cell); 0: slot unused
+  p.foldTab.assign((size_t)G * nInboxRows * T, 0u);
+  for (int j = 0; j < N; ++j)
+    if (inboxSlot[j] >= 0) {
+      const int row = rowOfState[j], lane = laneOf[j];
+      const unsigned dc = (dcBase + (unsigned)(row * T + lane) * 8u) >> 3;
+      if (remoteNull[j] && (p.rows[row].sIdx < 0 || inboxSlot[j] >= nInboxSRows * T)) return no("internal: inbox S cell");
+      const unsigned scc = remoteNull[j] ? (unsigned)(p.rows[row].sIdx * T + lane) : 0xffffu;
+      p.foldTab[(size_t)part[j] * nInboxRows * T + (size_t)inboxSlot[j]] = dc | (scc << 16);
+    }
 
   // meta: mdl | ctx << 4 | bit29 real state | bit30 reference's last state | bit31 reference's state 0
   p.metaTab.assign((size_t)G * K * T, 0);
@@ -634,13 +634,13 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G) {
   for (int k = 0; k < K; ++k) {
     if (k) rows << ",";
     rows << "{" << p.rows[k].nOut << "," << p.rows[k].sIdx << "," << p.rows[k].kind << "," << p.rows[k].cls << "," << p.rows[k].full << ","
-         << p.rows[k].gIdx << "," << p.rows[k].gOut << "}";
+         << p.rows[k].gOut << "}";
   }
   defs << "-DDNAS_T=" << T << "\n-DDNAS_K=" << K << "\n-DDNAS_D=" << D << "\n-DDNAS_NS=" << p.NSm << "\n-DDNAS_SROWS=" << p.nSRows
-       << "\n-DDNAS_NCLS=" << p.nClasses << "\n-DDNAS_G=" << G << "\n-DDNAS_GROWS=" << nGRows << "\n-DDNAS_ROWS=" << rows.str();
+       << "\n-DDNAS_NCLS=" << p.nClasses << "\n-DDNAS_G=" << G << "\n-DDNAS_GROWS=" << nInboxRows << "\n-DDNAS_GSROWS=" << nInboxSRows << "\n-DDNAS_ROWS=" << rows.str();
   p.defines = defs.str();
   p.key = "T" + std::to_string(T) + "K" + std::to_string(K) + "D" + std::to_string(D) + "S" + std::to_string(p.nSRows) + "C" +
-          std::to_string(p.nClasses) + "G" + std::to_string(G) + "X" + std::to_string(nGRows) + "R" + rows.str();
+          std::to_string(p.nClasses) + "G" + std::to_string(G) + "X" + std::to_string(nInboxRows) + "x" + std::to_string(nInboxSRows) + "R" + rows.str();
   p.ok = true;
   return p;
 }

@@ -5,13 +5,13 @@
 //
 //  * every state gets a place = (member, row, thread); a thread evaluates its rows in order inside a
 //    sweep, and keeps the S and D cells of its states in registers
-//  * every state owns an accumulator DC that its in-edges are pushed into with an atomic fp64 max, and
-//    -- if it has null in-edges -- a second one, SC:
-//      - a state whose in-edges all come from its own member: LDS cells DC[row*T + thread] and SC in a
-//        stripe of T cells that its row shares ("S rows"), ds_max_f64
-//      - a state with an in-edge from another member of the cluster: cells in the cluster's exchange
-//        buffer in global memory ("G rows"), global_atomic_max_f64 at agent scope; its owner reads them
-//        with agent-scope loads.  ALL in-edges of such a state go through the exchange buffer.
+//  * every state owns an LDS accumulator DC[row*T + thread] that its in-edges are pushed into
+//    (ds_max_f64), and -- if it has null in-edges -- a second one, SC, in a stripe of T cells
+//    that its row shares ("S rows")
+//  * in a cluster, a state with an in-edge from ANOTHER member also owns a slot of its member's inbox:
+//    cells of the cluster's exchange buffer in global memory that the other members offer into
+//    (global_atomic_max_f64 at agent scope) and that the member folds into the state's LDS cells, slot
+//    r*T + t by thread t, once per sweep
 //  * a state's OUT-edges become per-thread 32-bit entries (kept in registers by the kernel):
 //      emit edge  D(dst) >= max(D+delExtend, S+delOpen) + score        (viterbi.cpp:123-125)
 //                 and, between columns, S(dst) >= S + score + noGap + sub   (viterbi.cpp:92-95)
@@ -31,16 +31,16 @@ namespace dnas {
 // null in-edges), and what all entries of the row have in common, which the kernel then does not decode per
 // lane: kind 1 = emit edges only, 2 = null edges only, 0 = both; cls = the common score class or -1;
 // full = every lane of the row holds a state with exactly nOut out-edges (no entry is empty);
-// gIdx = ordinal of the row among the G rows (accumulators in the exchange buffer) or -1;
 // gOut = 0: every entry of the row points into LDS, 1: every entry into the exchange buffer, 2: mixed
-struct RowShape { int nOut, sIdx, kind, cls, full, gIdx, gOut; };
+struct RowShape { int nOut, sIdx, kind, cls, full, gOut; };
 
 struct TierAPlan {
   bool ok = false;
   std::string whyNot;
   int T = 1024, K = 0, D = 0, N = 0, nSRows = 0, nClasses = 1, nEntries = 0;
   int G = 1;                      // work-groups per read (1: tier A)
-  int nGRows = 0;                 // rows whose accumulators live in the exchange buffer (0 when G == 1)
+  int nGRows = 0;                 // inbox rows: a member's inbox holds nGRows * T slots (0 when G == 1)
+  int nGSRows = 0;                // ... of which the first nGSRows * T also carry an S cell (states reached over a null edge)
   int NSm = 0;                    // lattice slots per member (= K*T)
   int NS = 0;                     // lattice slots per column (= G*K*T)
   std::vector<RowShape> rows;
@@ -51,6 +51,7 @@ struct TierAPlan {
   std::vector<int32_t> stateOf;   // [G*K*T] index (member*K + row)*T + thread -> state or -1
   std::vector<uint32_t> entTab;   // [G][nEntries][T]  out-edges, see viterbi_tiera.hip
   std::vector<uint32_t> metaTab;  // [G][K][T]  mdl | ctx<<4 | flags
+  std::vector<uint32_t> foldTab;  // [G][nGRows][T]  inbox slot -> LDS cells of its state (DC addr >> 3 | SC addr >> 3 << 16), 0: unused
   double score[4] = {0, 0, 0, 0};
   size_t ldsBytes = 0;
   double fillRatio = 0;           // real entries / padded entries

@@ -53,6 +53,7 @@ struct TierALaunch {
   // tier C (a cluster of work-groups per read): exchange buffers, sync blocks, clusters in this launch, reads in this launch
   double* xbuf;
   unsigned* syncWords;
+  const unsigned* foldTab;
   int nClusters;
   int nReads;
   unsigned long long timeoutTicks;
@@ -65,6 +66,7 @@ struct dnas_model {
   int maxClusters = 1;          // tier C: clusters that fit the GPU at once
   double* dXbuf = nullptr;      // tier C: exchange buffers, one per cluster
   unsigned* dSync = nullptr;    // tier C: sync blocks (64 u32 per cluster)
+  unsigned* dFoldTab = nullptr; // tier C: inbox slot -> LDS cells, per member
   size_t xStride = 0;           // doubles per cluster in dXbuf
   unsigned long long timeoutTicks = 0;
   std::vector<unsigned> syncCheck;   // host copies of the sync blocks of every launch of the last call (watchdog, placement census)
@@ -278,7 +280,9 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
             if (const char* s = opt("max_clusters")) m->maxClusters = std::max(1, atoi(s));
             m->xStride = 3 * (size_t)p.exchangeCells() + 8;
             if (hipMalloc((void**)&m->dXbuf, m->xStride * (size_t)m->maxClusters * sizeof(double)) != hipSuccess ||
-                hipMalloc((void**)&m->dSync, (size_t)m->maxClusters * 64 * sizeof(unsigned)) != hipSuccess)
+                hipMalloc((void**)&m->dSync, (size_t)m->maxClusters * 64 * sizeof(unsigned)) != hipSuccess ||
+                hipMalloc((void**)&m->dFoldTab, std::max<size_t>(p.foldTab.size(), 1) * 4) != hipSuccess ||
+                hipMemcpy(m->dFoldTab, p.foldTab.data(), p.foldTab.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
               throw std::runtime_error("tier C exchange buffer allocation failed");
             double seconds = 2.0;   // watchdog per lattice column (a column takes tens of microseconds)
             if (const char* s = opt("cluster_timeout_s")) seconds = std::max(0.001, atof(s));
@@ -338,6 +342,7 @@ extern "C" void dnas_model_destroy(dnas_model* m) {
   if (m->dSlotOf) (void)hipFree(m->dSlotOf);
   if (m->dXbuf) (void)hipFree(m->dXbuf);
   if (m->dSync) (void)hipFree(m->dSync);
+  if (m->dFoldTab) (void)hipFree(m->dFoldTab);
   if (m->module) (void)hipModuleUnload(m->module);
   if (m->dBatchRead) (void)hipFree(m->dBatchRead);
   if (m->dSlotOff) (void)hipFree(m->dSlotOff);
@@ -475,7 +480,7 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
     HIP_TRY(hipEventRecord(m->events[4 * b], m->stream));
     if (m->tier >= 1) {
       TierALaunch la{m->argsA, m->dEntTab, m->dMetaTab, d_bases, m->dReadOff, m->dBatchRead + s, m->dSlotOff + s,
-                     m->arena, d_out_loglike, m->dRounds, nullptr, nullptr, 0, nB, 0ull};
+                     m->arena, d_out_loglike, m->dRounds, nullptr, nullptr, nullptr, 0, nB, 0ull};
       unsigned grid = (unsigned)nB;
       if (m->tier == 2) {
         // a cluster of G work-groups per read, persistent over the reads of the launch.  Blocks b and b + 8 share
@@ -483,7 +488,7 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
         // 8 blocks apart, cluster = (b / 8 / G) * 8 + b % 8.
         const int G = m->plan.G;
         const int nClusters = std::min(nB, m->maxClusters);
-        la.xbuf = m->dXbuf; la.syncWords = m->dSync; la.nClusters = nClusters; la.timeoutTicks = m->timeoutTicks;
+        la.xbuf = m->dXbuf; la.syncWords = m->dSync; la.foldTab = m->dFoldTab; la.nClusters = nClusters; la.timeoutTicks = m->timeoutTicks;
         grid = (unsigned)(8 * G * ((nClusters + 7) / 8));
         const size_t nX = m->xStride * (size_t)nClusters;
         hipLaunchKernelGGL(fill_neginf_kernel, dim3((unsigned)((nX + 255) / 256)), dim3(256), 0, m->stream, m->dXbuf, nX);
@@ -657,7 +662,7 @@ extern "C" int dnas_tierc_precompile(const dnas_flat_model* fm, int32_t members,
     const dnas::TierAPlan p = members >= 2 ? dnas::buildClusterPlan(*fm, members) : dnas::buildSmallestClusterPlan(*fm);
     if (!p.ok) return dnas::fail(DNAS_E_UNSUPPORTED, p.whyNot);
     (void)dnas::jitCompile(p.defines, p.key);
-    const std::string msg = "tier C: G=" + std::to_string(p.G) + " K=" + std::to_string(p.K) + " exchange rows " + std::to_string(p.nGRows) +
+    const std::string msg = "tier C: G=" + std::to_string(p.G) + " K=" + std::to_string(p.K) + " inbox rows " + std::to_string(p.nGRows) +
                             " exchange edges " + std::to_string(p.crossEdges) + " lds=" + std::to_string(p.ldsBytes) + " entries=" +
                             std::to_string(p.nEntries) + " back=" + std::to_string(p.backEdgesOnWalk) + " " + p.key;
     if (note && note_cap) { strncpy(note, msg.c_str(), note_cap - 1); note[note_cap - 1] = 0; }
@@ -669,10 +674,11 @@ extern "C" int dnas_tierc_precompile(const dnas_flat_model* fm, int32_t members,
 
 // Analysis / test aid: the tier-C tables of a machine exactly as the kernel receives them (no GPU needed).
 // info[8] = {G, K, T, entries per member, S stripes, exchange rows, 0, 0}; every other output may be NULL:
-// row_shapes[K][7], entries[G][n_entries][T], meta[G][K][T], member_of[N], lds_index[N] = row*T + lane inside
-// the member, lattice_slot[N].
+// row_shapes[K][6], entries[G][n_entries][T], meta[G][K][T], member_of[N], lds_index[N] = row*T + lane inside
+// the member, lattice_slot[N], fold[G][inbox rows][T].
 extern "C" int dnas_tierc_plan(const dnas_flat_model* fm, int32_t members, int32_t* info, int32_t* row_shapes, uint32_t* entries,
-                               size_t entries_cap, uint32_t* meta, int32_t* member_of, int32_t* lds_index, int32_t* lattice_slot) {
+                               size_t entries_cap, uint32_t* meta, int32_t* member_of, int32_t* lds_index, int32_t* lattice_slot,
+                               uint32_t* fold) {
   if (!fm || !info) return dnas::fail(DNAS_E_INVALID, "null argument");
   try {
     const dnas::TierAPlan p = members >= 2 ? dnas::buildClusterPlan(*fm, members)
@@ -682,8 +688,8 @@ extern "C" int dnas_tierc_plan(const dnas_flat_model* fm, int32_t members, int32
     if (row_shapes)
       for (int k = 0; k < p.K; ++k) {
         const dnas::RowShape& r = p.rows[k];
-        const int v[7] = {r.nOut, r.sIdx, r.kind, r.cls, r.full, r.gIdx, r.gOut};
-        memcpy(row_shapes + 7 * k, v, sizeof v);
+        const int v[6] = {r.nOut, r.sIdx, r.kind, r.cls, r.full, r.gOut};
+        memcpy(row_shapes + 6 * k, v, sizeof v);
       }
     if (entries) {
       if (entries_cap < p.entTab.size()) return dnas::fail(DNAS_E_INVALID, "entry buffer too small");
@@ -695,6 +701,7 @@ extern "C" int dnas_tierc_plan(const dnas_flat_model* fm, int32_t members, int32
       for (size_t idx = 0; idx < p.stateOf.size(); ++idx)
         if (p.stateOf[idx] >= 0) lds_index[p.stateOf[idx]] = (int32_t)(idx % ((size_t)p.K * p.T));
     if (lattice_slot) memcpy(lattice_slot, p.slotOf.data(), (size_t)p.N * sizeof(int32_t));
+    if (fold && !p.foldTab.empty()) memcpy(fold, p.foldTab.data(), p.foldTab.size() * sizeof(uint32_t));
     return DNAS_OK;
   } catch (const std::exception& e) {
     return dnas::fail(DNAS_E_DEVICE, e.what());

@@ -23,18 +23,20 @@
 //
 // Machines beyond one CU ("tier C", DNAS_G > 1): a CLUSTER of DNAS_G work-groups shares a read; member g
 // owns a part of the states (host/plan.cpp cuts the machine along its depth-first walk).  Edges inside a
-// member work as above.  A state with an in-edge from another member keeps its accumulators in the
-// cluster's exchange buffer in global memory ("G rows"): offers go there with global_atomic_max_f64 and
-// the owner reads them with agent-scope loads, so the protocol is correct wherever the work-groups run;
-// the launcher places a cluster on one XCD (blockIdx b and b+8 share one) for speed only.  Termination is
+// member work as above.  A state with an in-edge from another member also owns a slot of its member's
+// INBOX in the cluster's exchange buffer in global memory: the other members offer into it with
+// global_atomic_max_f64, and thread t of the owner folds slot r*T + t into the state's LDS accumulators
+// once per sweep (agent-scope loads issued at the start of the sweep, ds_max at its end), so the protocol
+// is correct wherever the work-groups run; the launcher places a cluster on one XCD (blockIdx b and b+8
+// share one) for speed only.  Termination is
 // agreed in two levels: inside a work-group as before, across the cluster through a device-scope epoch
 // GE (bumped after every batch of exchange offers has completed) and one idle word per member.
 //
 // Compile-time parameters (-D):  DNAS_T threads, DNAS_K rows, DNAS_D dup lanes,
 //   DNAS_NS slots per member (= K*T), DNAS_SROWS S stripes, DNAS_NCLS distinct edge scores,
-//   DNAS_G members per cluster, DNAS_GROWS rows with accumulators in the exchange buffer,
-//   DNAS_ROWS  brace list of {out-edge entries (-1: row left empty), S stripe or -1, kind, cls, full, G-row ordinal
-//              or -1, gOut} per row; what all entries of a row have in common is not decoded per lane.
+//   DNAS_G members per cluster, DNAS_GROWS inbox slots per thread, the first DNAS_GSROWS of them with an S cell,
+//   DNAS_ROWS  brace list of {out-edge entries (-1: row left empty), S stripe or -1, kind, cls, full, gOut}
+//              per row; what all entries of a row have in common is not decoded per lane.
 #ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>   // hiprtc provides the device runtime implicitly
 #endif
@@ -44,9 +46,9 @@
 #endif
 
 // kind: 1 emit edges only, 2 null edges only, 0 both; cls: common score class or -1; full: no empty entry;
-// gIdx: ordinal among the rows whose accumulators live in the exchange buffer, or -1; gOut: 0 every entry of
-// the row points into LDS, 1 every entry into the exchange buffer, 2 mixed (bit 2 of the entry tells)
-struct RowShape { int nOut, sIdx, kind, cls, full, gIdx, gOut; };
+// gOut: 0 every entry of the row points into LDS, 1 every entry into another member's inbox, 2 mixed (bit 2
+// of the entry tells)
+struct RowShape { int nOut, sIdx, kind, cls, full, gOut; };
 constexpr RowShape kRows[DNAS_K] = {DNAS_ROWS};
 
 constexpr bool rowLive(int k) { return kRows[k].nOut >= 0; }      // nOut -1: the plan left the row empty
@@ -75,6 +77,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 #define DNAS_G 1
 #define DNAS_GROWS 0
 #endif
+#ifndef DNAS_GSROWS
+#define DNAS_GSROWS DNAS_GROWS
+#endif
 
 // kernel-argument block (mirrors runtime.hip TierAArgs)
 struct TierAArgs {
@@ -86,9 +91,9 @@ struct TierAArgs {
   double score[4];  // score table, score[0] == 0
 };
 
-// LDS map (bytes):  SC[SROWS*T] | pad | DC[NS - GROWS*T] | score[4] | sub[16] | len[8] | red[T/64] | epoch, idle[T/64], done, ge, abort (u32)
+// LDS map (bytes):  SC[SROWS*T] | pad | DC[NS] | score[4] | sub[16] | len[8] | red[T/64] | epoch, idle[T/64], done, ge, abort (u32)
 constexpr int kDCBase = DNAS_SROWS * DNAS_T * 8 + 64;
-constexpr int kTabBase = kDCBase + (DNAS_NS - DNAS_GROWS * DNAS_T) * 8;   // the exchange rows (the first GROWS rows) keep no cells in LDS
+constexpr int kTabBase = kDCBase + DNAS_NS * 8;
 
 // entries (host/plan.cpp packs them), one per out-edge; every field is one or two VALU
 // operations away from its use.  Destination in LDS:
@@ -96,8 +101,8 @@ constexpr int kTabBase = kDCBase + (DNAS_NS - DNAS_GROWS * DNAS_T) * 8;   // the
 //   [3:18)  byte address of the destination's DC cell, >> 3       ->  en & 0x3fff8
 //   [19:32) null edge: index of the destination's SC cell          ->  (en >> 16) & 0xfff8 is its byte address
 //           emit edge: 0x1ffc | emitted base                       ->  en >= 0xffe00000
-// destination in the cluster's exchange buffer (bit 2 set):
-//   [0:2) score class | [3:23) cell index -> en & 0x7ffff8 is its byte offset | bit 23 null edge | [24:26) emitted base
+// destination in another member's inbox (bit 2 set):
+//   [0:2) score class | [3:23) inbox cell -> en & 0x7ffff8 is its byte offset | bit 23 null edge | [24:26) emitted base
 //   0: no edge
 #define ENT_VALID(e) ((e) != 0u)
 #define ENT_EMIT(e) ((e) >= 0xffe00000u)
@@ -125,6 +130,9 @@ __device__ __forceinline__ void ldsWrite(char* base, unsigned byteOff, double v)
 }
 __device__ __forceinline__ void ldsMax(char* base, unsigned byteOff, double v) {
   __hip_atomic_fetch_max(reinterpret_cast<double*>(base + byteOff), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ double ldsMaxRtn(char* base, unsigned byteOff, double v) {   // returns what the cell held
+  return __hip_atomic_fetch_max(reinterpret_cast<double*>(base + byteOff), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // exchange buffer: 8-byte agent-scope atomics on both sides (the offers are performed at the memory
 // side, the owner's loads and clears bypass this CU's L1), so a hand-over needs no fence
@@ -158,16 +166,15 @@ constexpr double kFresh = __builtin_huge_val();   // "not evaluated in this colu
 #ifndef DNAS_NT_D
 #define DNAS_NT_D 1
 #endif
-// Cluster constants.  Exchange buffer of one cluster: XA.dc | XB.dc | XB.sc, kCells doubles each (XA: the
-// emit offers between columns, XB: the offers of the in-column fixpoint -- two sets, because a fast member
-// is already offering into the fixpoint while a slow one still reads its between-column cells), then the
-// two cells of the end-of-read reduction.  Sync block of one cluster (64 u32): [0] GE, [1] abort,
+// Cluster constants.  Exchange buffer of one cluster: XA.dc | XB.dc | XB.sc, kCells doubles each, cell
+// (member * GROWS + r) * T + t = inbox slot r*T + t of that member (XA: the emit offers between columns,
+// XB: the offers of the in-column fixpoint -- two sets, because a fast member is already offering into the
+// fixpoint while a slow one still folds its between-column cells), then the two cells of the end-of-read
+// reduction.  Sync block of one cluster (64 u32): [0] GE, [1] abort,
 // [2, 2+G) idle word per member, [40] placement census (OR of 1 << XCC id).
 constexpr int G_ = DNAS_G;
 constexpr unsigned kCells = (unsigned)DNAS_G * DNAS_GROWS * DNAS_T;
 constexpr unsigned kXStride = 3u * kCells + 8u;   // doubles per cluster
-constexpr bool rowG(int k) { return kRows[k].gIdx >= 0; }
-constexpr bool rowHasS(int k) { return kRows[k].gIdx >= 0 || kRows[k].sIdx >= 0; }
 
 extern "C" __global__ void __launch_bounds__(DNAS_T)
 viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kEntries][T]
@@ -176,8 +183,8 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
                    const int* __restrict__ batchRead, const unsigned long long* __restrict__ slotOff,
                    double* __restrict__ arena, double* __restrict__ outLoglike,
                    unsigned long long* __restrict__ roundsTotal,
-                   double* __restrict__ xbuf, unsigned* __restrict__ syncWords, int nClusters, int nReads,
-                   unsigned long long timeoutTicks) {
+                   double* __restrict__ xbuf, unsigned* __restrict__ syncWords, const unsigned* __restrict__ foldTab,   // [G][GROWS][T]
+                   int nClusters, int nReads, unsigned long long timeoutTicks) {
   extern __shared__ double lds[];
   extern __shared__ unsigned ldsU[];
   constexpr int T = DNAS_T, K = DNAS_K, D_ = DNAS_D, lanes = 2, NSm = DNAS_NS, NS = DNAS_NS * DNAS_G;   // stored lanes: S, D
@@ -209,6 +216,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
     SY = syncWords + (size_t)cluster * 64;
     entTab += (size_t)member * kEntries * T;
     metaTab += (size_t)member * K * T;
+    foldTab += (size_t)member * DNAS_GROWS * T;
     if (tid == 0) {
       unsigned xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -216,8 +224,15 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
     }
   }
   constexpr unsigned kXA = 0u, kXBd = kCells * 8u, kXBs = 2u * kCells * 8u, kXRed = 3u * kCells * 8u;
-  // own exchange cells of G row k: cell (member*GROWS + gIdx)*T + tid
-#define X_OWN(k) ((unsigned)(((unsigned)member * DNAS_GROWS + (unsigned)kRows[k].gIdx) * T + (unsigned)tid) * 8u)
+  // own inbox cells: slot r*T + tid of this member
+#define X_OWN(r) ((unsigned)(((unsigned)member * DNAS_GROWS + (unsigned)(r)) * T + (unsigned)tid) * 8u)
+  // where slot r*T + tid folds into: byte addresses of the state's DC and SC cells (0 / 0x7fff8: none)
+  constexpr int R_ = DNAS_GROWS > 0 ? DNAS_GROWS : 1;
+  unsigned FT[R_];
+  if constexpr (G_ > 1) static_for<0, DNAS_GROWS>([&](auto rc) { FT[rc.value] = foldTab[(size_t)rc.value * T + tid]; });
+#define FOLD_DC(f) (((f) & 0xffffu) << 3)
+#define FOLD_SC(f) (((f) >> 16) << 3)
+#define FOLD_HAS_SC(f) ((f) != 0u && ((f) >> 16) != 0xffffu)
 
   unsigned E[kEntries];
   static_for<0, kEntries>([&](auto m) { E[m.value] = entTab[(size_t)m.value * T + tid]; });
@@ -237,13 +252,13 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
   };
   // own accumulators: byte addresses
   const unsigned ownB = (unsigned)tid * 8u;
-#define DC_OWN(k) (ownB + (unsigned)kDCBase + (unsigned)((k) - DNAS_GROWS) * T * 8u)
+#define DC_OWN(k) (ownB + (unsigned)kDCBase + (unsigned)(k) * T * 8u)
 #define SC_OWN(k) (ownB + (unsigned)kRows[k].sIdx * T * 8u)
 
   double S[K], Dv[K];   // after phase C, Dv[k] carries the T1 hand-over to the next column's phase A
   unsigned rounds = 0;
 #ifdef DNAS_STAMP   // diagnostic build: where does a column spend its cycles (never in the shipped kernel)
-  unsigned long long tA = 0, tP = 0, tB = 0, tC = 0, t0 = 0, t1 = 0;
+  unsigned long long tA = 0, tP = 0, tB = 0, tC = 0, tX = 0, tW = 0, t0 = 0, t1 = 0, tw0 = 0;
 #define STAMP(acc) { t1 = __builtin_amdgcn_s_memtime(); acc += t1 - t0; t0 = t1; }
 #else
 #define STAMP(acc)
@@ -282,7 +297,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
   // ---- cluster synchronisation (tier C).  GE only grows.  geBase = its value when the cluster last agreed
   // (every member holds the same number); a column starts with one bump per member, which is the
   // barrier behind the between-column offers AND what makes the idle words of the previous column stale.
-  unsigned geBase = 0, colSeq = 0;
+  unsigned geBase = 0, colSeq = 0, xDirty = 0;
   bool aborted = false;
   unsigned long long tStart = 0ull;   // watchdog: a column that takes longer than timeoutTicks (100 MHz) aborts the launch
   // all offers of this work-group into the exchange buffer have completed -> bump -> wait for every member
@@ -357,24 +372,36 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
       });
     }
     if constexpr (G_ > 1) {
+      STAMP(tA)
       clusterBarrier();            // every member's offers of the previous column have landed
+      STAMP(tX)
       if (aborted) break;
     } else if (pos > 0) {
       __syncthreads();             // every offer of the previous column has landed
     }
     STAMP(tA)
     if (pos > 0) {
+      if constexpr (G_ > 1) {
+        // what the other members offered lands in the LDS cells of the states it was meant for
+        double xa[R_];
+        static_for<0, DNAS_GROWS>([&](auto rc) {   // all loads in flight together
+          xa[rc.value] = kNegInf;
+          if (FT[rc.value]) xa[rc.value] = xLoad(xB, kXA + X_OWN(rc.value));
+        });
+        static_for<0, DNAS_GROWS>([&](auto rc) {
+          constexpr int r = rc.value;
+          if (xa[r] > kNegInf) {
+            ldsMax(ldsB, FOLD_DC(FT[r]), xa[r]);
+            xStore(xB, kXA + X_OWN(r), kNegInf);      // nobody offers here again before the next column's barrier
+          }
+        });
+        __syncthreads();
+      }
       static_for<0, K>([&](auto kc) {
         constexpr int k = kc.value;
         if constexpr (rowLive(k)) {
-          // Dv: T1(pos-1) + sub[ctx1][x_pos], left there by phase C
-          if constexpr (rowG(k)) {
-            S[k] = dmax(xLoad(xB, kXA + X_OWN(k)), Dv[k]);
-            xStore(xB, kXA + X_OWN(k), kNegInf);      // nobody offers here again before the next column's barrier
-          } else {
-            S[k] = dmax(ldsRead(ldsB, DC_OWN(k)), Dv[k]);
-            ldsWrite(ldsB, DC_OWN(k), kNegInf);
-          }
+          S[k] = dmax(ldsRead(ldsB, DC_OWN(k)), Dv[k]);   // Dv: T1(pos-1) + sub[ctx1][x_pos], left there by phase C
+          ldsWrite(ldsB, DC_OWN(k), kNegInf);
           Dv[k] = kFresh;
         }
       });
@@ -402,8 +429,8 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
     // row) within one sweep -- the plan lays the machine's chains out along ascending rows.
     //
     // Cluster: the same one level up.  GE is bumped by a wave after its exchange offers have completed
-    // (s_waitcnt vmcnt(0) in between, and again before the wave may call itself idle, so that its own bump
-    // has landed).  Wave 0 reads GE in every sweep and turns a change into a bump of the work-group's
+    // (in its next sweep, behind an s_waitcnt vmcnt(0); a sweep that offered something is never the idle
+    // one; and s_waitcnt vmcnt(0) again before the wave may call itself idle, so that its own bump has landed).  Wave 0 reads GE in every sweep and turns a change into a bump of the work-group's
     // epoch: every wave then sweeps once more, i.e. reads its exchange cells AFTER that value of GE was
     // seen.  A work-group whose waves are all idle, and whose wave 0 still reads the GE it last imported,
     // writes GE+1 into its idle word; when every member's word says GE+1 and GE is still the same,
@@ -412,29 +439,40 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
       constexpr int NW = DNAS_T / 64;
       const int wv = tid >> 6, ln = tid & 63;
       unsigned geSeen = geBase;
+      bool pendingBump = false;
+      xDirty = 0;
       for (;;) {
         asm volatile("" ::: "memory");   // other waves write LDS between sweeps: reload everything
         const unsigned e0 = __hip_atomic_load(epochL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (ln == 0) __hip_atomic_store(&idleL[wv], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         int changed = 0, sentX = 0;
         unsigned geNow = geSeen;
-        if constexpr (G_ > 1) { if (wv == 0) geNow = wLoad(&SY[0]); }
+        // the inbox is folded at the end of the sweep: its cells are loaded now and have arrived by then
+        double xd[R_], xs[DNAS_GSROWS > 0 ? DNAS_GSROWS : 1];
+        if constexpr (G_ > 1) {
+          if (wv == 0) geNow = wLoad(&SY[0]);
+          static_for<0, DNAS_GROWS>([&](auto rc) {
+            constexpr int r = rc.value;
+            xd[r] = kNegInf;
+            if (FT[r]) xd[r] = xLoad(xB, kXBd + X_OWN(r));
+            if constexpr (r < DNAS_GSROWS) {
+              xs[r] = kNegInf;
+              if (FOLD_HAS_SC(FT[r])) xs[r] = xLoad(xB, kXBs + X_OWN(r));
+            }
+          });
+        }
         static_for<0, K>([&](auto kc) {
           constexpr int k = kc.value, o = rowOffset(k);
           if constexpr (!rowLive(k)) return;
+
           // D is exactly what the in-edges have offered; a row with no S cells can only move when D
           // moved.  The first sweep of a column finds Dv == kFresh (no D cell is ever +inf) and offers
           // the starting values.
           double d, s = S[k];
-          if constexpr (rowG(k)) {
-            d = xLoad(xB, kXBd + X_OWN(k));
-            s = dmax(s, xLoad(xB, kXBs + X_OWN(k)));
-          } else {
-            d = ldsRead(ldsB, DC_OWN(k));
-            if constexpr (kRows[k].sIdx >= 0) s = dmax(s, ldsRead(ldsB, SC_OWN(k)));
-          }
+          d = ldsRead(ldsB, DC_OWN(k));
+          if constexpr (kRows[k].sIdx >= 0) s = dmax(s, ldsRead(ldsB, SC_OWN(k)));
           bool grew = d != Dv[k];
-          if constexpr (rowHasS(k)) grew = grew || s != S[k];
+          if constexpr (kRows[k].sIdx >= 0) grew = grew || s != S[k];
           if (grew) {
             changed = 1;
             s = dmax(s, d + a.delEnd);                                 // viterbi.cpp:114-115
@@ -475,10 +513,22 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
         });
         ++rounds;
         if constexpr (G_ > 1) {
-          if (__any(sentX)) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the exchange offers are performed ...
-            if (ln == 0) __hip_atomic_fetch_add(&SY[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before GE says so
+          // fold the inbox: a cell that raises its state's LDS accumulator counts like an offer of this wave
+          static_for<0, DNAS_GROWS>([&](auto rc) {
+            constexpr int r = rc.value;
+            if (xd[r] > kNegInf) { xDirty |= 1u << r; if (ldsMaxRtn(ldsB, FOLD_DC(FT[r]), xd[r]) < xd[r]) changed = 1; }
+            if constexpr (r < DNAS_GSROWS) {
+              if (xs[r] > kNegInf) { xDirty |= 0x100u << r; if (ldsMaxRtn(ldsB, FOLD_SC(FT[r]), xs[r]) < xs[r]) changed = 1; }
+            }
+          });
+          // the loads above were issued after the exchange offers of the previous sweep and have returned, so those
+          // offers have completed (a wave's memory operations complete in order): GE may say so now
+          if (pendingBump) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (ln == 0) __hip_atomic_fetch_add(&SY[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pendingBump = false;
           }
+          if (__any(sentX)) pendingBump = true;   // GE is bumped once these offers have completed: in the next sweep
           if (wv == 0 && geNow != geSeen) { geSeen = geNow; changed = 1; }   // import: everybody sweeps once more
         }
         if (__any(changed)) {
@@ -504,6 +554,9 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
               break;
             }
             bool declared = false;
+#ifdef DNAS_STAMP
+            tw0 = __builtin_amdgcn_s_memtime();
+#endif
             for (unsigned spin = 0;; ++spin) {
               const unsigned w = ln < 2 + G_ ? wLoad(&SY[ln]) : 0u;
               const unsigned ge = __shfl(w, 0, 64), ab = __shfl(w, 1, 64);
@@ -537,6 +590,9 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
               }
               __builtin_amdgcn_s_sleep(2);
             }
+#ifdef DNAS_STAMP
+            tW += __builtin_amdgcn_s_memtime() - tw0;
+#endif
             break;
           }
           if (__hip_atomic_load(epochL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != e0) break;   // someone grew a cell: sweep again
@@ -567,6 +623,15 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
       // the D lane leaves first: its registers then carry the T1 hand-over (one store latency ahead
       // of the history loads, instead of 28 more live registers)
       STORE_LANE(pos, 1, Dv)
+      if constexpr (G_ > 1) {
+        // the inbox cells that were offered into are cleared for the next column's fixpoint (every offer was seen by
+        // the last sweep; nobody offers into XB again before the next column's barrier)
+        static_for<0, DNAS_GROWS>([&](auto rc) {
+          constexpr int r = rc.value;
+          if (xDirty & (1u << r)) xStore(xB, kXBd + X_OWN(r), kNegInf);
+          if (xDirty & (0x100u << r)) xStore(xB, kXBs + X_OWN(r), kNegInf);
+        });
+      }
       const int xn = pos < L ? seq[pos] : 0;
       int xh[D_ > 0 ? D_ : 1];   // xh[i] = x_{pos-i}
       static_for<0, D_>([&](auto ic) { xh[ic.value] = pos - ic.value >= 1 ? seq[pos - ic.value - 1] : 0; });
@@ -601,13 +666,8 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
           if constexpr (!rowLive(k)) { Dv[k] = kNegInf; return; }
           const double s = S[k];
           const int mdl = (int)(metaG[k - k0] & 15u);
-          if constexpr (rowG(k)) {
-            xStore(xB, kXBd + X_OWN(k), kNegInf);
-            xStore(xB, kXBs + X_OWN(k), kNegInf);
-          } else {
-            ldsWrite(ldsB, DC_OWN(k), kNegInf);
-            if constexpr (kRows[k].sIdx >= 0) ldsWrite(ldsB, SC_OWN(k), kNegInf);
-          }
+          ldsWrite(ldsB, DC_OWN(k), kNegInf);
+          if constexpr (kRows[k].sIdx >= 0) ldsWrite(ldsB, SC_OWN(k), kNegInf);
           // T1(pos): chain from the deepest element (i = D-1) to i = 0.  Nearly every state has a
           // full context (mdl == D) and nearly every column a full history: that case is straight
           // line code, chosen per wave.
@@ -653,7 +713,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
   }
   if (aborted) break;
 #ifdef DNAS_STAMP
-  if (tid == 0 && blockIdx.x == 0) { roundsTotal[1] = tA; roundsTotal[2] = tP; roundsTotal[3] = tB; roundsTotal[4] = tC; roundsTotal[5] = (unsigned long long)rounds; }
+  if (tid == 0 && blockIdx.x == 0) { roundsTotal[1] = tA; roundsTotal[2] = tP; roundsTotal[3] = tB; roundsTotal[4] = tC; roundsTotal[5] = (unsigned long long)rounds; roundsTotal[6] = tX; roundsTotal[7] = tW; }
 #endif
 
   // ---- loglike (viterbi.h:102); local mode overwrites the end state with the column max

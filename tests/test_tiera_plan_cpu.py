@@ -18,7 +18,7 @@ def _decode_plan(fm, members):
     N = a["n_states"]
     pl = fm.cluster_plan(members)
     G, K, T, shapes, ent = pl["G"], pl["K"], pl["T"], pl["shapes"], pl["entries"]
-    n_s, n_g = pl["n_s_rows"], pl["n_g_rows"]
+    n_s, n_in, fold = pl["n_s_rows"], pl["n_inbox_rows"], pl["fold"]
     member_of, lds_idx = pl["member_of"], pl["lds_index"]
     dc_base = n_s * T * 8 + 64
     row_off = np.concatenate([[0], np.cumsum(np.maximum(shapes[:, 0], 0))])
@@ -30,7 +30,7 @@ def _decode_plan(fm, members):
         g = int(member_of[j])
         k, t = divmod(int(lds_idx[j]), T)
         assert shapes[k, 0] >= 0, "state placed in a row the plan marks empty"
-        kind, cls_common, g_out = shapes[k, 2], shapes[k, 3], shapes[k, 6]
+        kind, cls_common, g_out = shapes[k, 2], shapes[k, 3], shapes[k, 5]
         for e in range(int(shapes[k, 0])):
             en = int(ent[g, row_off[k] + e, t])
             if en == 0:
@@ -38,21 +38,25 @@ def _decode_plan(fm, members):
                 continue
             cls = en & 3
             assert cls_common < 0 or cls == cls_common
-            if en & 4:                                            # destination in the exchange buffer
+            if en & 4:                                            # destination in another member's inbox
                 assert g_out in (1, 2)
                 cell = (en >> 3) & 0xfffff
-                dg, rest = divmod(cell, n_g * T)
-                drow, dlane = divmod(rest, T)
-                assert shapes[drow, 5] == drow, "exchange cell outside the exchange rows"
-                dst = int(state_at[dg, drow * T + dlane])
+                dg, slot = divmod(cell, n_in * T)
+                assert dg != g, "inbox entry into the own member"
+                f = int(fold[dg, slot // T, slot % T])            # the fold table says which LDS cells the slot feeds
+                assert f != 0, "offer into an unused inbox slot"
+                dst_idx = ((f & 0xffff) * 8 - dc_base) // 8
+                dst = int(state_at[dg, dst_idx])
                 is_null = bool(en & 0x800000)
                 base = (en >> 24) & 3
+                drow = dst_idx // T
+                if is_null:
+                    assert (f >> 16) != 0xffff and (f >> 16) == shapes[drow, 1] * T + dst_idx % T, "inbox S cell is not the destination's"
             else:
                 assert g_out in (0, 2)
-                dst_idx = ((en & 0x3fff8) - dc_base) // 8 + n_g * T   # the exchange rows keep no cells in LDS
+                dst_idx = ((en & 0x3fff8) - dc_base) // 8
                 dst = int(state_at[g, dst_idx])
                 drow = dst_idx // T
-                assert shapes[drow, 5] < 0, "LDS entry into an exchange row"
                 is_null = en < 0xffe00000
                 base = (en >> 19) & 3
                 if is_null:
@@ -62,12 +66,11 @@ def _decode_plan(fm, members):
             assert kind == 0 or kind == (2 if is_null else 1)
             out[j].append((dst, cls, base, is_null))
     rows = lds_idx // T
-    has_s = (shapes[rows, 1] >= 0) | (shapes[rows, 5] >= 0)
-    # an edge between two members must go through the exchange buffer (the destination sits in an exchange row)
-    for j in range(N):
-        for dst, _, _, _ in out[j]:
-            if member_of[dst] != member_of[j]:
-                assert shapes[rows[dst], 5] >= 0
+    has_s = shapes[rows, 1] >= 0
+    # every used inbox slot belongs to exactly one state
+    used = fold[fold != 0] & 0xffff if G > 1 else np.zeros(0, dtype=np.uint32)
+    per_member = [sorted((fold[g][fold[g] != 0] & 0xffff).tolist()) for g in range(G)] if G > 1 else []
+    assert all(len(set(v)) == len(v) for v in per_member)
     return out, has_s
 
 
