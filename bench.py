@@ -1,16 +1,25 @@
 #!/usr/bin/env python3
-"""Headline benchmark: decoded nt/s, Viterbi error decoding on the s16h74l4c4 composite.
+"""Benchmarks of the hot path on MI355X, one BASELINE.json configuration per run (`--config`, index into
+BASELINE.json `configs`; the default, 2, is the configuration the metric is quoted on):
 
-Workload (BASELINE.json configs[2], SURVEY.md 8(d) "Config 3"): per GPU `--reads` synthetic
-reads, each 29 random payload bytes (MT19937, seed 1000 + read index) encoded through
-data/s16h74l4c4.json (479-505 nt), 1 % i.i.d. substitutions; error model --error-global with
-the CLI defaults (sub .01, iv 10, dup .001, del-open .001, del-ext .01, P = 6).  A "step" is
-one pass of the hot path (lattice fill + traceback for every read of the shard) with the
-reads already resident in HBM; with N > 1 ranks the per-GPU work is fixed (weak scaling) and
-the decoded strings are gathered to rank 0 inside the timed region.
+  1  Viterbi -V on the mixradar6 composite (flusher * mixradar6 * l4c4, 46 670 states, README.md:34-47), ~1 kb reads
+     (128 random payload bytes), --error-global; the fill runs on clusters of work-groups (tier C).  BASELINE names
+     a single read: its latency is reported as `latency_ms_single_read`; the throughput line uses `--reads` reads.
+  2  10 000 x ~490-nt reads per GPU through s16h74l4c4.json (12 361 states), --error-global  [headline]
+  3  ~1 kb reads through water64.1 * l4c4 (7 066 states: the composable reading of "water64.1 + hamming74", SURVEY
+     8d 4a), 12 500 reads per GPU (100k over 8 GPUs); `--variant b`: hamming74 * dropdot * water64.1 * l4c4
+     (258 538 states, tier C), 16 reads per GPU
+  4  forward-backward E-step (expectedCounts, fwdback.cpp:190-209), 256-nt pairs with dup + sub + del errors,
+     125 000 pairs per GPU (1M over 8 GPUs); unit nt/s over the read (output) lengths
+
+Reads are synthetic and deterministic per read index: random payload (MT19937, seed 1000 + index) encoded through
+the machine, 1 % i.i.d. substitutions; error model = CLI defaults, P = 6.  A "step" is one pass of the hot path
+(lattice fill + traceback of every read of the shard) with the reads resident in HBM; with N > 1 ranks the per-GPU
+work is fixed (weak scaling), every rank makes its own reads by index (`--scatter`: rank 0 makes all and scatters
+them over RCCL instead) and the decoded strings are gathered to rank 0 inside the timed region.
 
 Launch: `python bench.py` (1 GPU) or, for N > 1,
-`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
    --master-port P bench.py --gpus N --steps K --warmup W`.
 Rank 0 prints ONE JSON line.
 """
@@ -26,16 +35,45 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-MACHINE = os.path.join(ROOT, "tests", "golden", "ref_data", "s16h74l4c4.json")
+REF_DATA = os.path.join(ROOT, "tests", "golden", "ref_data")
+MACHINE = os.path.join(REF_DATA, "s16h74l4c4.json")
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+# the 3-state adaptor that swallows hamming74's flush symbol '.' (not part of the reference)
+DROPDOT = ('{"state":[{"n":0,"id":"S","trans":[{"in":"^","out":"^","to":1}]},{"n":1,"id":"T","trans":[{"in":"0","out":"0","to":1},'
+           '{"in":"1","out":"1","to":1},{"in":".","to":1},{"in":"$","out":"$","to":2}]},{"n":2,"id":"U","trans":[]}]}')
 
 
-def make_reads(machine, first_index, count, sub_rate=0.01):
-    """Config-3 generator: payload -> exact encoding -> i.i.d. substitutions.  Deterministic per read index."""
+def _compose(da, *parts):
+    ms = [p if isinstance(p, da.Machine) else da.Machine.fromFile(os.path.join(REF_DATA, p)) for p in parts]
+    m = ms[-1]
+    for a in reversed(ms[:-1]):
+        m = da.Machine.compose(a, m)
+    return m
+
+
+def workload(da, config, variant):
+    """-> dict(machine, payload_bytes, default_reads, name)."""
+    if config == 1:
+        return dict(machine=_compose(da, "flusher.json", "mixradar6.json", "l4c4.json"), payload_bytes=128, default_reads=96,
+                    name="configs[1]: ~980-nt reads through flusher*mixradar6*l4c4 (46670 states)")
+    if config == 2:
+        return dict(machine=da.Machine.fromFile(MACHINE), payload_bytes=29, default_reads=10000,
+                    name="configs[2]: ~490-nt reads through s16h74l4c4.json (12361 states)")
+    if config == 3 and variant == "b":
+        return dict(machine=_compose(da, "hamming74.json", da.Machine.fromJSON(DROPDOT), "water64.1.json", "l4c4.json"), payload_bytes=32,
+                    default_reads=16, name="configs[3] as written: ~1050-nt reads through hamming74*dropdot*water64.1*l4c4 (258538 states)")
+    if config == 3:
+        return dict(machine=_compose(da, "water64.1.json", "l4c4.json"), payload_bytes=56, default_reads=12500,
+                    name="configs[3] (4a): ~1050-nt reads through water64.1*l4c4 (7066 states)")
+    raise SystemExit("unknown --config %r" % config)
+
+
+def make_reads(machine, first_index, count, sub_rate=0.01, payload_bytes=29):
+    """Payload -> exact encoding -> i.i.d. substitutions.  Deterministic per read index."""
     reads = []
     for i in range(first_index, first_index + count):
         rng = random.Random(1000 + i)
-        payload = bytes(rng.randrange(256) for _ in range(29))
+        payload = bytes(rng.randrange(256) for _ in range(payload_bytes))
         dna = np.frombuffer(machine.encodeBytes(payload).encode(), dtype=np.uint8).copy()
         nrng = np.random.default_rng(1000 + i)
         hit = nrng.random(len(dna)) < sub_rate
@@ -48,23 +86,90 @@ def make_reads(machine, first_index, count, sub_rate=0.01):
     return reads
 
 
-def cpu_baseline(reads, max_seconds=20.0):
-    """Time the CPU oracle (the port of the reference's algorithm) on a bounded sample of the
-    same workload, single thread.  Checker code: used here only as the reported baseline."""
+# ----------------------------------------------------------------------------- CPU baseline (the oracle = the port)
+def host_cores():
+    """Host cores this job may really use: the affinity mask, cut by the cgroup CPU quota, and by the 16-core share a
+    one-GPU box of this pool gives a job (DNAS_BENCH_CORES overrides).  Oversubscribing would understate the CPU."""
+    if os.environ.get("DNAS_BENCH_CORES"):
+        return max(1, int(os.environ["DNAS_BENCH_CORES"]))
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, 16))
+
+
+def _cpu_worker(job):
+    """One host core: build the oracle for the machine, decode its reads, return (seconds, results)."""
+    machine_json, global_, reads = job
+    from oracle import oracle as O
+    orc = O.ViterbiOracle(O.Machine.from_json(machine_json), O.MutatorParams.from_cli(global_=global_))
+    t0 = time.perf_counter()
+    res = [orc.decode(r) for r in reads]
+    return time.perf_counter() - t0, res
+
+
+def cpu_baseline(machine_json, reads, seconds, max_nt=None):
+    """The CPU oracle (the port of the reference's algorithm) on a bounded sample of the same workload: first one
+    thread for ~seconds/3 (the one-core rate, which also sizes the sample), then one process per host core over
+    disjoint reads for ~seconds.  Checker code: used here only as the reported baseline and for the parity check.
+    max_nt: decode only a prefix of each read (machines whose single read takes the CPU a minute)."""
+    import multiprocessing as mp
     from oracle import oracle as O
     O.build()
-    orc = O.ViterbiOracle(O.Machine.from_file(MACHINE), O.MutatorParams.from_cli(global_=True))
-    nt, n, results = 0, 0, []
+    if max_nt:
+        reads = [r[:max_nt] for r in reads]
+    cores = host_cores()
+    orc = O.ViterbiOracle(O.Machine.from_json(machine_json), O.MutatorParams.from_cli(global_=True))
+    nt1, n1, results = 0, 0, {}
     t0 = time.perf_counter()
-    for r in reads:
-        results.append(orc.decode(r))
-        nt += len(r)
-        n += 1
-        if time.perf_counter() - t0 > max_seconds:
+    for i, r in enumerate(reads):
+        results[i] = orc.decode(r)
+        nt1 += len(r)
+        n1 += 1
+        if time.perf_counter() - t0 > seconds / 3.0:
             break
-    dt = time.perf_counter() - t0
-    return dict(value=nt / dt, unit="nt/s", cores=1, kind="port",
-                sample="%d reads (%d nt) of the same batch, oracle/viterbi_oracle.c, 1 thread, %.1f s" % (n, nt, dt)), results
+    dt1 = time.perf_counter() - t0
+    rate1 = nt1 / dt1
+    mean_len = max(1.0, nt1 / n1)
+    per_core = max(1, int(seconds * rate1 / mean_len))
+    jobs, at = [], n1
+    for _ in range(cores):
+        chunk = reads[at:at + per_core]
+        if not chunk:
+            break
+        jobs.append((machine_json, True, chunk))
+        at += len(chunk)
+    out = dict(value=rate1, unit="nt/s", cores=1, kind="port", value_one_core=rate1,
+               sample="%d reads (%d nt%s) of the same batch, oracle/viterbi_oracle.c, 1 thread, %.1f s" % (
+                   n1, nt1, ", first %d nt of each" % max_nt if max_nt else "", dt1))
+    if len(jobs) >= 2:
+        ctx = mp.get_context("spawn")
+        with ctx.Pool(len(jobs)) as pool:
+            pool.map(_cpu_worker, [(machine_json, True, j[2][:1]) for j in jobs])     # start-up (imports, machine parse) untimed
+            t0 = time.perf_counter()
+            parts = pool.map(_cpu_worker, jobs)
+            wall = time.perf_counter() - t0
+        nt = sum(len(r) for j in jobs for r in j[2])
+        pos = n1
+        for (_, res), j in zip(parts, jobs):
+            for k, rr in enumerate(res):
+                results[pos + k] = rr
+            pos += len(j[2])
+        out.update(value=nt / wall, cores=len(jobs),
+                   sample="%d reads (%d nt%s) of the same batch over %d processes (one per host core), oracle/viterbi_oracle.c, %.1f s wall; "
+                          "one core alone: %.0f nt/s" % (sum(len(j[2]) for j in jobs), nt, ", first %d nt of each" % max_nt if max_nt else "",
+                                                          len(jobs), wall, rate1))
+    return out, results
 
 
 def main():
@@ -72,10 +177,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=10000, help="reads per GPU (config 3: 10k)")
+    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3, 4], help="index into BASELINE.json configs (default 2: the headline)")
+    ap.add_argument("--variant", default="a", choices=["a", "b"], help="config 3: a = water64.1*l4c4, b = hamming74*dropdot*water64.1*l4c4")
+    ap.add_argument("--reads", type=int, default=0, help="reads (config 4: pairs) per GPU; 0 = the configuration's default")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline time budget (0 = skip)")
     ap.add_argument("--arena-gb", type=float, default=0.0, help="lattice arena per GPU (0 = the library's default, 60 %% of free HBM)")
+    ap.add_argument("--scatter", action="store_true", help="rank 0 makes every rank's reads and scatters them (RCCL) instead of per-rank generation")
+    ap.add_argument("--options", default=None, help='dnas_model_create_ex options, e.g. "max_slots=690"')
     args = ap.parse_args()
+    if args.config == 4:
+        import bench_fwdback
+        return bench_fwdback.main(args)
 
     import torch
     import torch.distributed as dist
@@ -104,21 +216,26 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    machine = da.Machine.fromFile(MACHINE)
+    wl = workload(da, args.config, args.variant)
+    machine = wl["machine"]
+    n_reads = args.reads or wl["default_reads"]
     params = da.MutatorParams.fromFlags(global_=True)
-    dec = da.ViterbiDecoder(machine, params, device=local_rank, arena_bytes=int(args.arena_gb * 1e9))
+    dec = da.ViterbiDecoder(machine, params, device=local_rank, arena_bytes=int(args.arena_gb * 1e9), options=args.options)
 
-    # ---- inputs: rank 0 makes the whole job's reads and scatters them (RCCL), untimed
-    total_reads = args.reads * world
-    all_reads = None
-    if rank == 0:
-        all_reads = make_reads(machine, 0, total_reads)
-        off_all, bases_all = da.pack_reads(all_reads)
+    # ---- inputs (untimed): every rank makes its own reads by index; --scatter: rank 0 makes all, RCCL scatter
+    my_reads = None
+    if args.scatter:
+        all_reads = make_reads(machine, 0, n_reads * world, payload_bytes=wl["payload_bytes"]) if rank == 0 else None
+        off_all, bases_all = da.pack_reads(all_reads) if rank == 0 else (None, None)
+        idx, off, d_bases = shard.scatter_reads(off_all, bases_all, world, rank, coll_device)
+        d_bases = d_bases.to(device)
+        if rank == 0:
+            my_reads = [all_reads[int(i)] for i in idx]
     else:
-        off_all, bases_all = None, None
-    idx, off, d_bases = shard.scatter_reads(off_all, bases_all, world, rank, coll_device)
-    d_bases = d_bases.to(device)
-    torch.cuda.synchronize()   # the library launches on its own streams: the scattered reads must have landed
+        my_reads = make_reads(machine, rank * n_reads, n_reads, payload_bytes=wl["payload_bytes"])
+        off, bases = da.pack_reads(my_reads)
+        d_bases = torch.from_numpy(bases).to(device)
+    torch.cuda.synchronize()   # the library launches on its own streams: the reads must have landed
     k = len(off) - 1
     lens = np.diff(off).astype(np.int64)
     cap = int(lens.max()) + 64 if k else 64
@@ -172,27 +289,51 @@ def main():
         total_nt = float(shard_nt)
 
     if rank == 0:
-        # ---- parity spot check + CPU baseline (rank 0, N = 1 only), outside the timed region
+        extra = {}
         cpu = None
-        if world == 1 and args.cpu_seconds > 0:
-            cpu, results = cpu_baseline(all_reads, args.cpu_seconds)
-            sym, olen, ll, st = [x.cpu().numpy() for x in gathered[0]]
-            for i, (s_ref, ll_ref) in enumerate(results):
-                got = sym[i * cap:i * cap + int(olen[i])].tobytes().decode()
-                if got != s_ref or float(ll[i]) != ll_ref:
-                    raise SystemExit("PARITY FAILURE on read %d: %r/%r vs oracle %r/%r" % (i, got, ll[i], s_ref, ll_ref))
-            cpu["parity_checked_reads"] = len(results)
+        if world == 1:
+            # ---- the same shard through the host-pointer entry point (dnas_viterbi_batch): H2D of the reads, D2H of the
+            # decoded strings, per-call device buffers -- SURVEY 8(d)'s PCIe-inclusive rate; never `value`
+            dec.decode(my_reads[:min(k, 64)])
+            tp = time.perf_counter()
+            out_h, ll_h, st_h = dec.decode(my_reads)
+            extra["value_pcie_inclusive"] = shard_nt / (time.perf_counter() - tp)
+            # ---- BASELINE configs[1] names ONE read: its latency
+            if args.config == 1:
+                dec.decode(my_reads[:1])
+                tp = time.perf_counter()
+                dec.decode(my_reads[:1])
+                extra["latency_ms_single_read"] = (time.perf_counter() - tp) * 1e3
+                extra["fill_ms_single_read"] = dec.stats()["fill_ms"]
+            # ---- parity spot check + CPU baseline (rank 0, N = 1 only), outside the timed region
+            if args.cpu_seconds > 0:
+                max_nt = 256 if machine.nStates() > 100000 else None
+                cpu, results = cpu_baseline(machine.toJSON(), my_reads, args.cpu_seconds, max_nt=max_nt)
+                sym, olen, ll, st = [x.cpu().numpy() for x in gathered[0]]
+                if max_nt:      # prefixes were decoded on the CPU: decode the same prefixes on the GPU
+                    idxs = sorted(results)
+                    pre_out, pre_ll, _ = dec.decode([my_reads[i][:max_nt] for i in idxs])
+                    got = {i: (pre_out[j], float(pre_ll[j])) for j, i in enumerate(idxs)}
+                else:
+                    got = {i: (sym[i * cap:i * cap + int(olen[i])].tobytes().decode(), float(ll[i])) for i in results}
+                for i, (s_ref, ll_ref) in results.items():
+                    if got[i][0] != s_ref or got[i][1] != ll_ref:
+                        raise SystemExit("PARITY FAILURE on read %d: %r/%r vs oracle %r/%r" % (i, got[i][0], got[i][1], s_ref, ll_ref))
+                cpu["parity_checked_reads"] = len(results)
         value = total_nt * args.steps / elapsed
         launches = stats["fill_launches"] * args.steps
         achieved = stats["lattice_bytes"] * args.steps / (fill_ms / 1e3) / 1e9 if fill_ms > 0 else 0.0
-        # HBM traffic of the fill kernel: PMC counters are collected in separate rocprofv3 passes of this same
-        # command (profiles/r1_traffic.json: FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md, + WRITE_SIZE,
-        # in KB), recorded per lattice column and scaled here to the columns of one launch
-        traffic = None
+        tier = dec.tier[:6]
+        # HBM traffic of the fill kernel from PMC counters is collected in separate rocprofv3 passes (profiles/README.md)
+        # and is NOT measured in this run: the field carries a recorded per-column figure only when a profile of this
+        # configuration and kernel specialisation exists, with its source named; otherwise null.
+        traffic, traffic_source = None, None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
-            if tj.get("kernel", "").endswith("tiera") == dec.tier.startswith("tier A"):
+            src = os.path.join("profiles", "r2_traffic_config%d%s.json" % (args.config, args.variant if args.config == 3 else ""))
+            tj = json.load(open(os.path.join(ROOT, src)))
+            if tj.get("tier") == tier:
                 traffic = tj["hbm_bytes_per_column_corrected"] * stats["columns"] / max(stats["fill_launches"], 1)
+                traffic_source = "%s (separate rocprofv3 --pmc passes of this command, per column, scaled to this run's columns per launch)" % src
         except (OSError, ValueError, KeyError):
             pass
         line = {
@@ -200,18 +341,21 @@ def main():
             "value": value, "unit": "nt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[2]: %d x ~490-nt reads/GPU through s16h74l4c4.json (12361 states), "
-                                   "--error-global, 1%% substitutions" % args.reads,
-                       "reads_per_gpu": args.reads, "total_nt": int(total_nt), "parallelism": "read-sharded x%d" % world},
+            "config": {"workload": "%s, %d reads/GPU, --error-global, 1%% substitutions" % (wl["name"], n_reads),
+                       "reads_per_gpu": n_reads, "total_nt": int(total_nt), "parallelism": "read-sharded x%d" % world,
+                       "inputs": "rank 0 scatter (RCCL)" if args.scatter else "generated per rank by read index"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "viterbi_fill_tiera" if dec.tier.startswith("tier A") else "viterbi_fill_kernel",
-                         "tier": dec.tier[:6], "avg_launch_ms": fill_ms / max(launches, 1),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "frac_whole_step": stats["lattice_bytes"] * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
+                         "kernel": "viterbi_fill_tiera" if tier in ("tier A", "tier C") else "viterbi_fill_kernel",
+                         "tier": tier, "avg_launch_ms": fill_ms / max(launches, 1),
                          "algorithmic_bytes_per_launch": stats["lattice_bytes"] / max(stats["fill_launches"], 1),
+                         "algorithmic_bytes_per_column": 8 * (dec.max_dup_len + 2) * dec.n_states,
                          "rounds_per_column": stats["rounds"] / max(stats["columns"], 1),
                          "traceback_ms_per_step": tb_ms / args.steps},
             "cpu_baseline": cpu,
         }
+        line.update(extra)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -34,7 +34,7 @@ for it in range(repeat):
     print("%d reads, %d nt: wall %.1f ms, fill %.1f ms (%d launches), traceback %.1f ms; %.0f nt/s by fill; %.1f us/column/cluster-slot; sweeps/col/wg %.1f; "
           "canonical roofline frac %.3f; census %s; status ok %s" % (
               n, nt, dt * 1e3, s["fill_ms"], s["fill_launches"], s["traceback_ms"], nt / (s["fill_ms"] / 1e3),
-              s["fill_ms"] * 1e3 / s["columns"] * min(n, int(dec.tier.split(",")[1].split()[0])), s["rounds"] / s["columns"], frac, dec.cluster_census(), not st.any()), flush=True)
+              s["fill_ms"] * 1e3 / s["columns"] * min(n, (int(dec.tier.split(",")[1].split()[0]) if dec.tier.startswith("tier C") else 256)), s["rounds"] / s["columns"], frac, dec.cluster_census(), not st.any()), flush=True)
 if "DNAS_STAMP" in os.environ.get("DNAS_TIERA_DEFS", ""):
     import ctypes
     from dnastore_amd import lib as L
@@ -42,7 +42,7 @@ if "DNAS_STAMP" in os.environ.get("DNAS_TIERA_DEFS", ""):
     L.check(L.lib().dnas_model_debug_words(dec._h, w))
     w = list(w)
     cols = len(reads[0]) + 1     # block 0 = member 0 of cluster 0 = read 0 (last of its reads: stamps accumulate over them)
-    nreads0 = (n + min(n, int(dec.tier.split(",")[1].split()[0])) - 1) // min(n, int(dec.tier.split(",")[1].split()[0]))
+    nreads0 = (n + min(n, (int(dec.tier.split(",")[1].split()[0]) if dec.tier.startswith("tier C") else 256)) - 1) // min(n, (int(dec.tier.split(",")[1].split()[0]) if dec.tier.startswith("tier C") else 256))
     cols *= nreads0
     print("block 0, per column (100 MHz ticks -> us): offers %.2f  barrier %.2f  take %.2f  fixpoint %.2f (of which wave 0 in the cluster vote %.2f)  phase C %.2f; sweeps/col %.1f" % (
         w[1] / cols / 100, w[6] / cols / 100, w[2] / cols / 100, w[3] / cols / 100, w[7] / cols / 100, w[4] / cols / 100, w[5] / cols))
