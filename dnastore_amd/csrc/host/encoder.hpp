@@ -1,39 +1,30 @@
-// Exact (noise-free) encoder: input symbols -> DNA through a Machine, tracking the set
-// of states the transducer may be in together with each one's pending output, as the
-// reference's Encoder<Writer> does (src/encoder.h:7-243).  Used to make synthetic reads
-// (bench.py, tests) and by the CLI's --encode-* arms.
+// Exact (noise-free) encoder: input symbols -> DNA through a Machine (behaviour of the reference's
+// Encoder<Writer>, src/encoder.h:7-243): a Frontier fed along the input tape, plus the framing rules of the input
+// stream -- start-of-file is sent first when the machine can take it, a symbol the machine cannot take is
+// preceded by a flush, end-of-file is sent on close.  Used to make synthetic reads (bench.py, tests) and by the
+// CLI's --encode-* arms.
 #pragma once
-#include <map>
 #include <string>
 #include <vector>
 
-#include "machine.hpp"
+#include "frontier.hpp"
 
 namespace dnas {
 
 class Encoder {
  public:
-  explicit Encoder(const Machine& machine);
-  void encodeSymbol(char sym);                 // encoder.h:143-186
+  explicit Encoder(const Machine& machine) : frontier_(machine, Frontier::kFeedInput) {}
+  void encodeSymbol(char sym);
   void encodeSymbolString(const std::string& s) { for (char c : s) encodeSymbol(c); }
-  void encodeByte(unsigned char byte);         // LSB first, encoder.h:222-231
+  void encodeByte(unsigned char byte);         // bits LSB first (encoder.h:222-231)
   void encodeBytes(const std::string& bytes) { for (unsigned char c : bytes) encodeByte(c); }
-  void close();                                // encoder.h:33-57
-  const std::string& output() const { return out_; }
+  void close();
+  const std::string& output() const { return frontier_.settled(); }
   const std::vector<std::string>& warnings() const { return warnings_; }
 
  private:
-  typedef std::map<uint32_t, std::string> StateString;
-  bool canEncodeSymbol(char sym) const;
-  void expand();                               // encoder.h:76-121
-  void shiftResolvedSymbols();                 // encoder.h:188-216
-  static bool exitsWithInput(const MachineState& ms);
-  static bool emitsOutput(const MachineState& ms);
-
-  const Machine& machine_;
-  StateString current_;
-  bool sentSOF_ = false, sentEOF_ = false, closed_ = false;
-  std::string out_;
+  Frontier frontier_;
+  bool started_ = false, ended_ = false, closed_ = false;
   std::vector<std::string> warnings_;
 };
 

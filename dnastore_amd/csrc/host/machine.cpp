@@ -4,6 +4,7 @@
 #include <fstream>
 #include <ostream>
 #include <set>
+#include <unordered_map>
 #include <sstream>
 #include <stdexcept>
 
@@ -123,168 +124,184 @@ std::string Machine::outputAlphabet() const {
   return std::string(alph.begin(), alph.end());
 }
 
+// Order of the states such that every usable transition that emits nothing runs forwards (the first sweep of a
+// lattice column visits the states in this order, so that what such a transition carries is final when it is
+// read; reference behaviour: Machine::decoderToposort, trans.cpp:604-634).  Built on a compressed adjacency of
+// the non-emitting usable transitions: states whose last incoming one has been placed queue up first in, first out.
 std::vector<uint32_t> Machine::decoderToposort(const std::string& inAlph) const {
   const size_t n = state.size();
-  std::vector<int> nParents(n, 0);
-  std::vector<std::vector<uint32_t>> children(n);
-  long edges = 0;
-  for (size_t s = 0; s < n; ++s)
+  auto silent = [&](const MachineTransition& t) { return !t.out && (!t.in || inAlph.find(t.in) != std::string::npos); };
+  std::vector<uint32_t> start(n + 1, 0), waitingFor(n, 0);
+  for (size_t s = 0; s < n; ++s) {
     for (const auto& t : state[s].trans)
-      if (!t.out && (!t.in || inAlph.find(t.in) != std::string::npos)) {
-        ++nParents[t.dest];
-        ++edges;
-        children[s].push_back(t.dest);
-      }
-  std::deque<uint32_t> ready;
-  for (size_t s = 0; s < n; ++s)
-    if (!nParents[s]) ready.push_back((uint32_t)s);
+      if (silent(t)) { ++start[s + 1]; ++waitingFor[t.dest]; }
+  }
+  for (size_t s = 0; s < n; ++s) start[s + 1] += start[s];
+  std::vector<uint32_t> target(start[n]);
+  {
+    std::vector<uint32_t> at(start.begin(), start.end() - 1);
+    for (size_t s = 0; s < n; ++s)
+      for (const auto& t : state[s].trans)
+        if (silent(t)) target[at[s]++] = t.dest;
+  }
   std::vector<uint32_t> order;
   order.reserve(n);
-  while (!ready.empty()) {
-    const uint32_t u = ready.front();
-    ready.pop_front();
-    order.push_back(u);
-    for (uint32_t c : children[u]) {
-      --edges;
-      if (--nParents[c] == 0) ready.push_back(c);
-    }
+  for (size_t s = 0; s < n; ++s)
+    if (waitingFor[s] == 0) order.push_back((uint32_t)s);
+  for (size_t head = 0; head < order.size(); ++head) {     // `order` is its own queue
+    const uint32_t u = order[head];
+    for (uint32_t e = start[u]; e < start[u + 1]; ++e)
+      if (--waitingFor[target[e]] == 0) order.push_back(target[e]);
   }
-  if (edges > 0) throw std::domain_error("Transducer is cyclic, can't toposort");
+  if (order.size() < n) throw std::domain_error("Transducer is cyclic, can't toposort");
   return order;
 }
 
 namespace {
 
-bool hasInputEdge(const MachineState& s) {
-  for (const auto& t : s.trans) if (t.in) return true;
-  return false;
+// how a state leaves: only by reading input (it waits), only without reading (it runs), both (mixed), not at all (final)
+enum class Exit { kFinal, kWaits, kRuns, kMixed };
+Exit exitOf(const MachineState& s) {
+  bool reading = false, free = false;
+  for (const auto& t : s.trans) (t.in ? reading : free) = true;
+  return reading ? (free ? Exit::kMixed : Exit::kWaits) : (free ? Exit::kRuns : Exit::kFinal);
 }
-bool hasFreeEdge(const MachineState& s) {
-  for (const auto& t : s.trans) if (!t.in) return true;
-  return false;
-}
-// a state either waits for input on every edge, or moves without input on every edge, or is final
-bool isWait(const MachineState& s) { return hasInputEdge(s) && !hasFreeEdge(s); }
-bool isNonWait(const MachineState& s) { return !hasInputEdge(s) && hasFreeEdge(s); }
 
 }  // namespace
 
 bool Machine::isWaitingMachine() const {
   for (const auto& ms : state)
-    if (!isWait(ms) && !isNonWait(ms) && !ms.trans.empty()) return false;
+    if (exitOf(ms) == Exit::kMixed) return false;
   return true;
 }
 
+// Every state either waits or runs: a mixed state X is cut into "X;n", which keeps the transitions that read
+// nothing and gains one more to "X;w" directly behind it, which keeps the reading ones.  (A final state is cut the
+// same way -- the saved machines of the reference have it so, and its file format is the contract: trans.cpp:636-670.)
 Machine Machine::waitingMachine() const {
-  // A mixed state X (input edges and free edges) becomes "X;n" holding the free edges plus a null
-  // edge to a new state "X;w" (appended at the end) that holds the input edges.
-  std::vector<MachineState> pool(state);
-  std::vector<uint32_t> oldToNew(nStates()), order;
+  auto cut = [](const MachineState& ms) { const Exit e = exitOf(ms); return e == Exit::kMixed || e == Exit::kFinal; };
+  std::vector<uint32_t> placeOf(nStates());
+  uint32_t place = 0;
   for (uint32_t s = 0; s < nStates(); ++s) {
-    const MachineState& ms = state[s];
-    oldToNew[s] = (uint32_t)order.size();
-    order.push_back(s);
-    if (!isWait(ms) && !isNonWait(ms)) {   // mixed (the reference also splits end states, harmlessly)
-      MachineState freePart, waitPart;
-      freePart.name = ms.name + ";n";
-      waitPart.name = ms.name + ";w";
-      freePart.leftContext = waitPart.leftContext = ms.leftContext;
-      freePart.rightContext = waitPart.rightContext = ms.rightContext;
-      for (const auto& t : ms.trans) (t.in ? waitPart : freePart).trans.push_back(t);
-      MachineTransition hop;
-      hop.dest = (uint32_t)pool.size();
-      freePart.trans.push_back(hop);
-      oldToNew.push_back((uint32_t)order.size());
-      order.push_back((uint32_t)pool.size());
-      pool[s] = std::move(freePart);
-      pool.push_back(std::move(waitPart));
-    }
+    placeOf[s] = place;
+    place += cut(state[s]) ? 2u : 1u;
   }
   Machine wm;
-  for (uint32_t idx : order) {
-    MachineState ms = pool[idx];
-    for (auto& t : ms.trans) t.dest = oldToNew[t.dest];
-    wm.state.push_back(std::move(ms));
+  wm.state.reserve(place);
+  for (uint32_t s = 0; s < nStates(); ++s) {
+    const MachineState& ms = state[s];
+    if (!cut(ms)) {
+      wm.state.push_back(ms);
+      for (auto& t : wm.state.back().trans) t.dest = placeOf[t.dest];
+      continue;
+    }
+    MachineState runs, waits;
+    runs.name = ms.name + ";n";
+    waits.name = ms.name + ";w";
+    runs.leftContext = waits.leftContext = ms.leftContext;
+    runs.rightContext = waits.rightContext = ms.rightContext;
+    for (MachineTransition t : ms.trans) {
+      t.dest = placeOf[t.dest];
+      (t.in ? waits : runs).trans.push_back(t);
+    }
+    MachineTransition handOver;
+    handOver.dest = placeOf[s] + 1;
+    runs.trans.push_back(handOver);
+    wm.state.push_back(std::move(runs));
+    wm.state.push_back(std::move(waits));
   }
   return wm;
 }
 
+// first * second: what `first` writes is what `second` reads.  A state of the product is a pair (i, j); while j
+// waits, i moves (and each symbol it writes takes j along), otherwise j runs on its own.  Only the pairs that the
+// start pair can reach are ever made (a worklist from (0, 0)); of those, the ones from which the final pair cannot
+// be reached are dropped, a pair whose only way on is one transition that neither reads nor writes is folded into
+// where that chain ends, and the survivors are numbered by (i, j) -- the numbering, names and transition order of
+// the reference's product (trans.cpp:505-602), so that a saved composite is the same file.
 Machine Machine::compose(const Machine& first, const Machine& origSecond) {
   const Machine second = origSecond.isWaitingMachine() ? origSecond : origSecond.waitingMachine();
   if (first.state.empty() || second.state.empty()) throw std::runtime_error("Machine has no states");
   if (!first.state.back().trans.empty() || !second.state.back().trans.empty())
     throw std::runtime_error("Last state must be end state");
-  const size_t nB = second.nStates(), nAll = first.nStates() * nB;
-  auto id = [&](size_t i, size_t j) { return i * nB + j; };
-  std::vector<MachineState> prod(nAll);
-  for (size_t i = 0; i < first.nStates(); ++i)
-    for (size_t j = 0; j < nB; ++j) {
-      const MachineState& a = first.state[i];
-      const MachineState& b = second.state[j];
-      MachineState& ms = prod[id(i, j)];
-      ms.name = "(" + a.name + "," + b.name + ")";
-      ms.leftContext = b.leftContext;
-      ms.rightContext = b.rightContext;
-      if (isWait(b) || b.trans.empty()) {
-        // B waits: A moves; what A emits must be consumed by an input edge of B
-        for (const auto& ta : a.trans) {
-          if (!ta.out) {
-            MachineTransition t; t.in = ta.in; t.out = 0; t.dest = (uint32_t)id(ta.dest, j);
-            ms.trans.push_back(t);
-          } else {
-            for (const auto& tb : b.trans)
-              if (ta.out == tb.in) {
-                MachineTransition t; t.in = ta.in; t.out = tb.out; t.dest = (uint32_t)id(ta.dest, tb.dest);
-                ms.trans.push_back(t);
-              }
-          }
-        }
-      } else {
-        // B moves on its own
-        for (const auto& tb : b.trans) {
-          MachineTransition t; t.in = 0; t.out = tb.out; t.dest = (uint32_t)id(i, tb.dest);
-          ms.trans.push_back(t);
-        }
+  const uint64_t nB = second.nStates();
+  struct Pair { uint64_t key; std::vector<MachineTransition> trans; std::vector<uint32_t> from; bool reachesEnd = false; };
+  std::vector<Pair> pairs;                              // in order of discovery
+  std::unordered_map<uint64_t, uint32_t> found;         // key i*nB + j -> index into pairs
+  auto visit = [&](uint64_t i, uint64_t j) -> uint32_t {
+    const uint64_t key = i * nB + j;
+    auto it = found.find(key);
+    if (it != found.end()) return it->second;
+    found.emplace(key, (uint32_t)pairs.size());
+    pairs.push_back(Pair{key, {}, {}, false});
+    return (uint32_t)pairs.size() - 1;
+  };
+  visit(0, 0);
+  for (uint32_t at = 0; at < pairs.size(); ++at) {      // `pairs` grows while it is walked
+    const uint64_t i = pairs[at].key / nB, j = pairs[at].key % nB;
+    const MachineState& a = first.state[i];
+    const MachineState& b = second.state[j];
+    std::vector<MachineTransition> out;
+    auto add = [&](char in, char outSym, uint64_t di, uint64_t dj) {
+      MachineTransition t;
+      t.in = in; t.out = outSym; t.dest = visit(di, dj);    // index into pairs for now
+      out.push_back(t);
+    };
+    const Exit eb = exitOf(b);
+    if (eb == Exit::kWaits || eb == Exit::kFinal) {
+      for (const auto& ta : a.trans) {
+        if (!ta.out) { add(ta.in, 0, ta.dest, j); continue; }
+        for (const auto& tb : b.trans)
+          if (tb.in == ta.out) add(ta.in, tb.out, ta.dest, tb.dest);
       }
+    } else {
+      for (const auto& tb : b.trans) add(0, tb.out, i, tb.dest);
     }
-  // keep states reachable from the start that can still reach the end
-  std::vector<char> fwd(nAll, 0), bwd(nAll, 0);
-  std::deque<uint32_t> queue;
-  queue.push_back((uint32_t)id(0, 0));
-  fwd[queue.front()] = 1;
-  while (!queue.empty()) {
-    const uint32_t c = queue.front(); queue.pop_front();
-    for (const auto& t : prod[c].trans) if (!fwd[t.dest]) { fwd[t.dest] = 1; queue.push_back(t.dest); }
+    pairs[at].trans = std::move(out);
   }
-  std::vector<std::vector<uint32_t>> sources(nAll);
-  for (uint32_t s = 0; s < nAll; ++s) for (const auto& t : prod[s].trans) sources[t.dest].push_back(s);
-  queue.push_back((uint32_t)id(first.nStates() - 1, nB - 1));
-  bwd[queue.front()] = 1;
-  while (!queue.empty()) {
-    const uint32_t c = queue.front(); queue.pop_front();
-    for (uint32_t s : sources[c]) if (!bwd[s]) { bwd[s] = 1; queue.push_back(s); }
-  }
-  auto live = [&](uint32_t s) { return fwd[s] && bwd[s]; };
-  // a state whose only move is a null transition is merged into where that chain ends
-  std::vector<int64_t> merged(nAll, -1);
-  for (uint32_t s = 0; s < nAll; ++s)
-    if (live(s)) {
-      uint32_t d = s;
-      while (prod[d].trans.size() == 1 && !prod[d].trans.front().in && !prod[d].trans.front().out) d = prod[d].trans.front().dest;
-      if (d != s) merged[s] = d;
+  for (uint32_t s = 0; s < pairs.size(); ++s)
+    for (const auto& t : pairs[s].trans) pairs[t.dest].from.push_back(s);
+  // which pairs can still reach the final pair
+  {
+    const auto last = found.find((uint64_t)(first.nStates() - 1) * nB + (nB - 1));
+    std::vector<uint32_t> todo;
+    if (last != found.end()) { pairs[last->second].reachesEnd = true; todo.push_back(last->second); }
+    while (!todo.empty()) {
+      const uint32_t c = todo.back();
+      todo.pop_back();
+      for (uint32_t s : pairs[c].from)
+        if (!pairs[s].reachesEnd) { pairs[s].reachesEnd = true; todo.push_back(s); }
     }
-  std::vector<uint32_t> renum(nAll, 0);
-  uint32_t kept = 0;
-  for (uint32_t s = 0; s < nAll; ++s) if (live(s) && merged[s] < 0) renum[s] = kept++;
-  for (uint32_t s = 0; s < nAll; ++s) if (live(s) && merged[s] >= 0) renum[s] = renum[(size_t)merged[s]];
+  }
+  // fold the chains of lone empty transitions; number what is left by key
+  auto passesOn = [&](uint32_t s) {
+    const auto& ts = pairs[s].trans;
+    return ts.size() == 1 && !ts.front().in && !ts.front().out;
+  };
+  std::vector<uint32_t> standsFor(pairs.size());
+  for (uint32_t s = 0; s < pairs.size(); ++s) {
+    uint32_t d = s;
+    while (passesOn(d)) d = pairs[d].trans.front().dest;
+    standsFor[s] = d;
+  }
+  std::vector<uint32_t> kept;
+  for (uint32_t s = 0; s < pairs.size(); ++s)
+    if (pairs[s].reachesEnd && standsFor[s] == s) kept.push_back(s);
+  std::sort(kept.begin(), kept.end(), [&](uint32_t x, uint32_t y) { return pairs[x].key < pairs[y].key; });
+  std::vector<uint32_t> number(pairs.size(), 0);
+  for (uint32_t n = 0; n < kept.size(); ++n) number[kept[n]] = n;
   Machine out;
-  out.state.reserve(kept);
-  for (uint32_t s = 0; s < nAll; ++s)
-    if (live(s) && merged[s] < 0) {
-      MachineState ms = prod[s];
-      for (auto& t : ms.trans) t.dest = renum[t.dest];
-      out.state.push_back(std::move(ms));
-    }
+  out.state.reserve(kept.size());
+  for (uint32_t s : kept) {
+    const uint64_t i = pairs[s].key / nB, j = pairs[s].key % nB;
+    MachineState ms;
+    ms.name = "(" + first.state[i].name + "," + second.state[j].name + ")";
+    ms.leftContext = second.state[j].leftContext;
+    ms.rightContext = second.state[j].rightContext;
+    ms.trans = pairs[s].trans;
+    for (auto& t : ms.trans) t.dest = number[standsFor[t.dest]];
+    out.state.push_back(std::move(ms));
+  }
   return out;
 }
 
