@@ -293,14 +293,37 @@ def read_fastseqs(path):
     return out
 
 
-def decode_fastseqs(filename, machine, params, device=0):
-    """decodeFastSeqs(filename, machine, params) (viterbi.cpp:306-320) -> [(name, decoded symbols, loglike)]."""
+def format_event(ev):
+    """One traceback event as the reference's level-3 log line (viterbi.cpp:266-293)."""
+    kind, pos, pay = ev >> 62, (ev >> 32) & 0x3fffffff, ev & 0xffffffff
+    if kind == 1:
+        return "Substitution at %d: %s -> %s" % (pos, "ACGT"[(pay >> 2) & 3], "ACGT"[pay & 3])
+    if kind == 2:
+        return "Deletion between %d and %d: %s" % (pos - 1, pos, "ACGT"[pay & 3])
+    n = pay >> 16
+    return "Duplication at %d: %s" % (pos, "".join("ACGT"[(pay >> (2 * (n - 1 - i))) & 3] for i in range(n)))
+
+
+def decode_fastseqs(filename, machine, params, device=0, events=False, info=None):
+    """decodeFastSeqs(filename, machine, params) (viterbi.cpp:306-320) -> [(name, decoded symbols, loglike)]
+    (with events=True: [(name, symbols, loglike, [event lines])]).  device=-1: every GPU of the node.
+    info: an optional dict that receives the fill tier and the number of devices used."""
     h = ctypes.c_void_p()
-    _l.check(_l.lib().dnas_decode_fastseqs(str(filename).encode(), machine._h, ctypes.byref(params.c), int(device),
-                                           ctypes.byref(h)))
+    _l.check(_l.lib().dnas_decode_fastseqs_ex(str(filename).encode(), machine._h, ctypes.byref(params.c), int(device),
+                                              int(bool(events)), ctypes.byref(h)))
     L = _l.lib()
-    out = [(L.dnas_decoded_name(h, i).decode(), L.dnas_decoded_seq(h, i).decode(), L.dnas_decoded_loglike(h, i))
-           for i in range(L.dnas_decoded_count(h))]
+    out = []
+    for i in range(L.dnas_decoded_count(h)):
+        rec = (L.dnas_decoded_name(h, i).decode(), L.dnas_decoded_seq(h, i).decode(), L.dnas_decoded_loglike(h, i))
+        if events:
+            p = ctypes.c_void_p()
+            n = L.dnas_decoded_events(h, i, ctypes.byref(p))
+            evs = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint64)), shape=(n,)).copy() if n else []
+            rec = rec + ([format_event(int(e)) for e in evs],)
+        out.append(rec)
+    if info is not None:
+        info["tier"] = L.dnas_decoded_tier(h).decode()
+        info["devices"] = L.dnas_decoded_devices(h)
     L.dnas_decoded_free(h)
     return out
 

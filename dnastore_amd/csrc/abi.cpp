@@ -1,7 +1,10 @@
 // Host-only half of the C ABI (include/dnastore_amd.h): file formats, flattening and the
 // decodeFastSeqs convenience call.  The device half lives in runtime.hip.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <thread>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -23,6 +26,9 @@ struct dnas_pairs { dnas::AlignmentPairs db; dnas_pairs_view view; };
 struct dnas_decoded {
   std::vector<dnas::FastSeq> seqs;
   std::vector<double> loglike;
+  std::vector<std::vector<uint64_t>> events;   // per read, when asked for
+  std::string tier;                            // which fill kernel served the machine
+  int devices = 1;
 };
 
 namespace dnas {
@@ -274,55 +280,134 @@ int dnas_mutator_counts_json(const double* counts, int32_t n_len, char* buf, siz
   });
 }
 
-// decodeFastSeqs (viterbi.cpp:306-320): read the FASTA, build the input model once,
-// decode every read on the GPU, keep names, drop comments.
-int dnas_decode_fastseqs(const char* fasta_path, const dnas_machine* m, const dnas_mutator_params* p, int device_id,
-                         dnas_decoded** out) {
-  if (!fasta_path || !m || !p || !out) return dnas::fail(DNAS_E_INVALID, "null argument");
-  *out = nullptr;
-  dnas_flat* flat = nullptr;
+// decodeFastSeqs (viterbi.cpp:306-320): read the FASTA, build the input model once, decode every read on the GPU,
+// keep names, drop comments.  device_id >= 0: that GPU.  device_id = -1: every GPU of the node -- the reads are dealt
+// over the devices by length in snake order (longest first: 0..n-1, n-1..0, ...; what shard.partition does for the
+// one-process-per-GPU bench), one host thread and one model per device, results back in file order.  The loop the
+// reference runs serially (viterbi.cpp:312-318) has no dependence between reads, so nothing is exchanged.
+static int decode_shard(const dnas_flat_model* fm, int device, const std::vector<dnas::FastSeq>& reads, const std::vector<int64_t>& mine,
+                        bool events, std::vector<std::string>* seqs, std::vector<double>* lls, std::vector<std::vector<uint64_t>>* evs,
+                        std::string* tier, std::string* err) {
   dnas_model* model = nullptr;
-  int rc = guarded([&] {
-    const std::vector<dnas::FastSeq> reads = dnas::readFastSeqs(fasta_path);
-    int r = dnas_flatten(m, p, &flat);
-    if (r != DNAS_OK) return r;
+  auto fail = [&](int rc) {
+    *err = dnas_last_error();
+    if (model) dnas_model_destroy(model);
+    return rc;
+  };
+  try {
     std::vector<uint64_t> off{0}, outOff{0};
     std::vector<uint8_t> bases;
-    for (const auto& fs : reads) {
-      const std::vector<uint8_t> tok = dnas::tokenizeDNA(fs.seq, fs.name);
+    for (int64_t i : mine) {
+      const std::vector<uint8_t> tok = dnas::tokenizeDNA(reads[(size_t)i].seq, reads[(size_t)i].name);
       bases.insert(bases.end(), tok.begin(), tok.end());
       off.push_back(bases.size());
       outOff.push_back(outOff.back() + 4 * tok.size() + 64);
     }
-    dnas_decoded* d = new dnas_decoded();
-    const int64_t n = (int64_t)reads.size();
-    if (n > 0) {
-      r = dnas_model_create(dnas_flat_view(flat), device_id, 0, &model);
-      if (r != DNAS_OK) { delete d; return r; }
-      std::vector<char> sym(outOff.back());
-      std::vector<uint32_t> len(n);
-      std::vector<double> ll(n);
-      std::vector<uint8_t> st(n);
-      if (bases.empty()) bases.push_back(0);
-      r = dnas_viterbi_batch(model, n, off.data(), bases.data(), sym.data(), outOff.data(), len.data(), ll.data(), st.data());
-      if (r != DNAS_OK) { delete d; return r; }
-      for (int64_t i = 0; i < n; ++i) {
-        if (st[i] == DNAS_READ_OUT_OVERFLOW || st[i] == DNAS_READ_TRACEBACK_FAIL) {
-          delete d;
-          return dnas::fail(DNAS_E_DEVICE, st[i] == DNAS_READ_OUT_OVERFLOW ? "decoded string overflowed its slot"
-                                                                            : "Traceback failure");
-        }
-        dnas::FastSeq fs;
-        fs.name = reads[i].name;  // viterbi.cpp:315: name kept, comment dropped
-        fs.seq.assign(sym.data() + outOff[i], len[i]);
-        d->seqs.push_back(std::move(fs));
-        d->loglike.push_back(ll[i]);
+    const int64_t n = (int64_t)mine.size();
+    if (n == 0) return DNAS_OK;
+    int rc = dnas_model_create(fm, device, 0, &model);
+    if (rc != DNAS_OK) return fail(rc);
+    *tier = dnas_model_tier(model);
+    if (events) (void)dnas_model_set_event_log(model, 1);
+    std::vector<char> sym(outOff.back());
+    std::vector<uint32_t> len((size_t)n);
+    std::vector<double> ll((size_t)n);
+    std::vector<uint8_t> st((size_t)n);
+    if (bases.empty()) bases.push_back(0);
+    rc = dnas_viterbi_batch(model, n, off.data(), bases.data(), sym.data(), outOff.data(), len.data(), ll.data(), st.data());
+    if (rc != DNAS_OK) return fail(rc);
+    for (int64_t k = 0; k < n; ++k) {
+      if (st[(size_t)k] == DNAS_READ_OUT_OVERFLOW || st[(size_t)k] == DNAS_READ_TRACEBACK_FAIL) {
+        dnas::lastErrorSlot() = st[(size_t)k] == DNAS_READ_OUT_OVERFLOW ? "decoded string overflowed its slot" : "Traceback failure";
+        return fail(DNAS_E_DEVICE);
+      }
+      (*seqs)[(size_t)mine[(size_t)k]].assign(sym.data() + outOff[(size_t)k], len[(size_t)k]);
+      (*lls)[(size_t)mine[(size_t)k]] = ll[(size_t)k];
+      if (events) {
+        int64_t ne = 0;
+        rc = dnas_model_read_events(model, k, nullptr, 0, &ne);
+        if (rc != DNAS_OK) return fail(rc);
+        std::vector<uint64_t>& e = (*evs)[(size_t)mine[(size_t)k]];
+        e.resize((size_t)ne);
+        if (ne && (rc = dnas_model_read_events(model, k, e.data(), ne, &ne)) != DNAS_OK) return fail(rc);
       }
     }
-    *out = d;
+    dnas_model_destroy(model);
+    return DNAS_OK;
+  } catch (const std::exception& e) {
+    *err = e.what();
+    if (model) dnas_model_destroy(model);
+    return DNAS_E_DEVICE;
+  }
+}
+
+int dnas_decode_fastseqs(const char* fasta_path, const dnas_machine* m, const dnas_mutator_params* p, int device_id,
+                         dnas_decoded** out) {
+  return dnas_decode_fastseqs_ex(fasta_path, m, p, device_id, 0, out);
+}
+
+int dnas_decode_fastseqs_ex(const char* fasta_path, const dnas_machine* m, const dnas_mutator_params* p, int device_id,
+                            int want_events, dnas_decoded** out) {
+  if (!fasta_path || !m || !p || !out) return dnas::fail(DNAS_E_INVALID, "null argument");
+  *out = nullptr;
+  dnas_flat* flat = nullptr;
+  int rc = guarded([&] {
+    const std::vector<dnas::FastSeq> reads = dnas::readFastSeqs(fasta_path);
+    int r = dnas_flatten(m, p, &flat);
+    if (r != DNAS_OK) return r;
+    const int64_t n = (int64_t)reads.size();
+    // which devices
+    std::vector<int> devices;
+    if (device_id >= 0) {
+      devices.push_back(device_id);
+    } else {
+      int have = dnas_device_count();
+      if (have <= 0) return dnas::fail(DNAS_E_DEVICE, "no HIP device available");
+      int use = have;
+      if (const char* s = getenv("DNAS_FAKE_DEVICES")) use = std::max(1, atoi(s));   // tests: several host threads share the GPUs there are
+      for (int d = 0; d < use && d < std::max<int64_t>(n, 1); ++d) devices.push_back(d % have);
+    }
+    // deal the reads: by length, longest first, in snake order
+    std::vector<int64_t> order((size_t)n);
+    for (int64_t i = 0; i < n; ++i) order[(size_t)i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return reads[(size_t)a].seq.size() > reads[(size_t)b].seq.size(); });
+    const size_t W = devices.size();
+    std::vector<std::vector<int64_t>> shard(W);
+    for (size_t pos = 0; pos < order.size(); ++pos) {
+      const size_t round = pos / W, k = pos % W;
+      shard[round % 2 == 0 ? k : W - 1 - k].push_back(order[pos]);
+    }
+    for (auto& sh : shard) std::sort(sh.begin(), sh.end());
+    std::unique_ptr<dnas_decoded> d(new dnas_decoded());
+    std::vector<std::string> seqs((size_t)n);
+    std::vector<double> lls((size_t)n, 0.);
+    d->events.resize((size_t)n);
+    std::vector<int> rcs(W, DNAS_OK);
+    std::vector<std::string> errs(W), tiers(W);
+    if (W == 1) {
+      rcs[0] = decode_shard(dnas_flat_view(flat), devices[0], reads, shard[0], want_events != 0, &seqs, &lls, &d->events, &tiers[0], &errs[0]);
+    } else {
+      std::vector<std::thread> workers;
+      for (size_t w = 0; w < W; ++w)
+        workers.emplace_back([&, w] {
+          rcs[w] = decode_shard(dnas_flat_view(flat), devices[w], reads, shard[w], want_events != 0, &seqs, &lls, &d->events, &tiers[w], &errs[w]);
+        });
+      for (auto& t : workers) t.join();
+    }
+    for (size_t w = 0; w < W; ++w)
+      if (rcs[w] != DNAS_OK) return dnas::fail(rcs[w], "device " + std::to_string(devices[w]) + ": " + errs[w]);
+    for (int64_t i = 0; i < n; ++i) {
+      dnas::FastSeq fs;
+      fs.name = reads[(size_t)i].name;  // viterbi.cpp:315: name kept, comment dropped
+      fs.seq = std::move(seqs[(size_t)i]);
+      d->seqs.push_back(std::move(fs));
+      d->loglike.push_back(lls[(size_t)i]);
+    }
+    for (const auto& t : tiers) if (!t.empty()) { d->tier = t; break; }
+    d->devices = (int)W;
+    *out = d.release();
     return DNAS_OK;
   });
-  if (model) dnas_model_destroy(model);
   if (flat) dnas_flat_free(flat);
   return rc;
 }
@@ -331,6 +416,13 @@ int64_t dnas_decoded_count(const dnas_decoded* d) { return d ? (int64_t)d->seqs.
 const char* dnas_decoded_name(const dnas_decoded* d, int64_t i) { return d->seqs[(size_t)i].name.c_str(); }
 const char* dnas_decoded_seq(const dnas_decoded* d, int64_t i) { return d->seqs[(size_t)i].seq.c_str(); }
 double dnas_decoded_loglike(const dnas_decoded* d, int64_t i) { return d->loglike[(size_t)i]; }
+const char* dnas_decoded_tier(const dnas_decoded* d) { return d ? d->tier.c_str() : ""; }
+int dnas_decoded_devices(const dnas_decoded* d) { return d ? d->devices : 0; }
+int64_t dnas_decoded_events(const dnas_decoded* d, int64_t i, const uint64_t** events) {
+  if (!d || i < 0 || (size_t)i >= d->events.size()) return 0;
+  if (events) *events = d->events[(size_t)i].data();
+  return (int64_t)d->events[(size_t)i].size();
+}
 void dnas_decoded_free(dnas_decoded* d) { delete d; }
 
 }  // extern "C"

@@ -56,7 +56,7 @@ const char* kHelp =
     "  --error-counts arg            estimate posterior expected counts of various different types of error from Stockholm database\n"
     "  --strict-guides               treat alignments in Stockholm database as strict truth, not just hints\n"
     "  -v [ --verbose ] arg (=2)     verbosity level\n"
-    "  --device arg (=0)             GPU to use\n";
+    "  --device arg (=0)             GPU to use; -1 = every GPU of the node, reads dealt over them\n";
 
 [[noreturn]] void die(const std::string& msg) {
   std::cerr << msg << std::endl;
@@ -65,10 +65,13 @@ const char* kHelp =
 
 void check(int rc) {
   if (rc != DNAS_OK) {
-    // the reference prints e.what() and still exits 0 for exceptions caught in main
-    // (dnastore.cpp:245-250); missing files exit 1 (Fail, util.cpp:47-54)
+    // the reference prints e.what() and still exits 0 for the exceptions it catches in main
+    // (dnastore.cpp:245-250: parse errors, cyclic machines, ...); missing files exit 1 (Fail, util.cpp:47-54).
+    // Failures that are not reference exceptions -- no GPU, out of device memory, an unsupported or invalid
+    // request -- must not look like success: an empty stdout with exit 0 would feed empty decodes downstream.
     std::cerr << dnas_last_error() << std::endl;
-    exit(rc == DNAS_E_IO ? 1 : 0);
+    const bool referenceException = rc == DNAS_E_PARSE || rc == DNAS_E_CYCLIC || rc == DNAS_E_NOT_DNA || rc == DNAS_E_BAD_BASE;
+    exit(referenceException ? 0 : (rc == DNAS_E_IO ? 1 : 2));
   }
 }
 
@@ -238,9 +241,26 @@ int main(int argc, char** argv) {
     dnas_free(text);
   } else if (!o.decodeViterbi.empty()) {                            // dnastore.cpp:217-223
     dnas_decoded* dec = nullptr;
-    check(dnas_decode_fastseqs(o.decodeViterbi.c_str(), machine, &mut, o.device, &dec));
+    check(dnas_decode_fastseqs_ex(o.decodeViterbi.c_str(), machine, &mut, o.device, o.verbose >= 3, &dec));
+    if (o.verbose >= 3) std::cerr << "Viterbi fill: " << dnas_decoded_tier(dec) << "; devices: " << dnas_decoded_devices(dec) << std::endl;
     for (int64_t i = 0; i < dnas_decoded_count(dec); ++i) {
       const std::string seq = dnas_decoded_seq(dec, i);
+      if (o.verbose >= 3) {                                          // what the traceback found (viterbi.cpp:266-293)
+        const uint64_t* ev = nullptr;
+        const int64_t ne = dnas_decoded_events(dec, i, &ev);
+        static const char base[] = "ACGT";
+        for (int64_t k = 0; k < ne; ++k) {
+          const unsigned kind = (unsigned)(ev[k] >> 62), pos = (unsigned)((ev[k] >> 32) & 0x3fffffffu), pay = (unsigned)(ev[k] & 0xffffffffu);
+          if (kind == 1) std::cerr << "Substitution at " << pos << ": " << base[(pay >> 2) & 3] << " -> " << base[pay & 3] << std::endl;
+          else if (kind == 2) std::cerr << "Deletion between " << (long)pos - 1 << " and " << pos << ": " << base[pay & 3] << std::endl;
+          else if (kind == 3) {
+            std::string dup;
+            const unsigned cnt = pay >> 16;
+            for (unsigned q = 0; q < cnt; ++q) dup.push_back(base[(pay >> (2 * (cnt - 1 - q))) & 3]);
+            std::cerr << "Duplication at " << pos << ": " << dup << std::endl;
+          }
+        }
+      }
       if (seq.empty()) std::cerr << "No valid Viterbi decoding found" << std::endl;   // viterbi.cpp:198-201
       writeFasta(std::cout, dnas_decoded_name(dec, i), seq, o.raw);
     }

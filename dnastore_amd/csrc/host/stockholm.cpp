@@ -55,7 +55,7 @@ void addAlignment(AlignmentPairs& db, const std::vector<std::pair<std::string, s
 
 AlignmentPairs readStockholmPairs(const std::string& path) {
   std::ifstream in(path);
-  if (!in) throw std::runtime_error("File " + path + " not found");
+  if (!in) throw std::runtime_error("File not found: " + path);   // -> DNAS_E_IO (the reference: Fail, exit 1)
   AlignmentPairs db;
   db.inOff.push_back(0); db.outOff.push_back(0); db.cmInOff.push_back(0); db.cmOutOff.push_back(0);
   std::vector<std::pair<std::string, std::string>> rows;

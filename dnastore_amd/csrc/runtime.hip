@@ -22,7 +22,7 @@ extern "C" __global__ void expand_lattice_kernel(DevModel, const uint8_t*, const
 extern "C" __global__ void fill_neginf_kernel(double*, size_t);
 extern "C" __global__ void viterbi_traceback_kernel(DevModel, const uint8_t*, const uint64_t*, const int32_t*,
                                                     const uint64_t*, const double*, char*, const uint64_t*,
-                                                    uint32_t*, uint8_t*, int);
+                                                    uint32_t*, uint8_t*, int, unsigned long long*, const uint64_t*, uint32_t*);
 
 #define HIP_TRY(expr)                                                                          \
   do {                                                                                         \
@@ -101,6 +101,12 @@ struct dnas_model {
   std::vector<hipEvent_t> events;      // 4 per batch: fill start/end (stream), traceback start/end (stream2)
   dnas_batch_stats stats{};
   bool statsPending = false;
+  // optional traceback event log (the reference's level-3 messages): device buffers of the last call
+  bool eventLog = false;
+  unsigned long long* dEvents = nullptr;
+  uint64_t* dEvOff = nullptr;
+  uint32_t* dEvLen = nullptr;
+  std::vector<uint64_t> evOff;
 };
 
 namespace {
@@ -144,6 +150,12 @@ int collect_stats(dnas_model* m) {
 }  // namespace
 
 extern "C" int dnas_has_device_code(void) { return 1; }
+
+extern "C" int dnas_device_count(void) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+  return count;
+}
 
 extern "C" int dnas_model_create(const dnas_flat_model* fm, int device_id, size_t arena_bytes, dnas_model** out) {
   return dnas_model_create_ex(fm, device_id, arena_bytes, nullptr, out);
@@ -343,6 +355,9 @@ extern "C" void dnas_model_destroy(dnas_model* m) {
   if (m->dXbuf) (void)hipFree(m->dXbuf);
   if (m->dSync) (void)hipFree(m->dSync);
   if (m->dFoldTab) (void)hipFree(m->dFoldTab);
+  if (m->dEvents) (void)hipFree(m->dEvents);
+  if (m->dEvOff) (void)hipFree(m->dEvOff);
+  if (m->dEvLen) (void)hipFree(m->dEvLen);
   if (m->module) (void)hipModuleUnload(m->module);
   if (m->dBatchRead) (void)hipFree(m->dBatchRead);
   if (m->dSlotOff) (void)hipFree(m->dSlotOff);
@@ -448,6 +463,17 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
   HIP_TRY(hipMemcpy(m->dOutOff, out_offsets, ((size_t)n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
   HIP_TRY(hipMemsetAsync(m->dRounds, 0, 8 * sizeof(unsigned long long), m->stream));
 
+  if (m->dEvents) { (void)hipFree(m->dEvents); (void)hipFree(m->dEvOff); (void)hipFree(m->dEvLen); m->dEvents = nullptr; m->dEvOff = nullptr; m->dEvLen = nullptr; }
+  if (m->eventLog) {
+    // at most one event per traceback step: a read of L bases takes fewer than 2L + 8 + (null depth) steps
+    m->evOff.assign((size_t)n_reads + 1, 0);
+    for (int64_t i = 0; i < n_reads; ++i) m->evOff[(size_t)i + 1] = m->evOff[(size_t)i] + 3 * (read_offsets[i + 1] - read_offsets[i]) + 64;
+    HIP_TRY(hipMalloc((void**)&m->dEvents, std::max<size_t>(m->evOff.back(), 1) * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void**)&m->dEvOff, ((size_t)n_reads + 1) * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc((void**)&m->dEvLen, (size_t)n_reads * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(m->dEvOff, m->evOff.data(), ((size_t)n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(m->dEvLen, 0, (size_t)n_reads * sizeof(uint32_t)));
+  }
   const size_t nBatches = batchStart.size() - 1;
   while (m->events.size() < 4 * nBatches) {
     hipEvent_t e;
@@ -517,7 +543,7 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
     hipLaunchKernelGGL(viterbi_traceback_kernel, dim3((nB + kTraceThreads - 1) / kTraceThreads), dim3(kTraceThreads), 0,
                        m->stream2, d, d_bases, (const uint64_t*)m->dReadOff, (const int32_t*)(m->dBatchRead + s),
                        (const uint64_t*)(m->dSlotOff + s), (const double*)m->arena, d_out_sym,
-                       (const uint64_t*)m->dOutOff, d_out_len, d_out_status, nB);
+                       (const uint64_t*)m->dOutOff, d_out_len, d_out_status, nB, m->dEvents, (const uint64_t*)m->dEvOff, m->dEvLen);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(m->events[4 * b + 3], m->stream2));
     HIP_TRY(hipEventRecord(m->sync[2 * b + 1], m->stream2));
@@ -654,6 +680,29 @@ extern "C" int dnas_tiera_precompile(const dnas_flat_model* fm, char* note, size
 }
 
 extern "C" const char* dnas_model_tier(const dnas_model* m) { return m ? m->tierNote.c_str() : ""; }
+
+extern "C" int dnas_model_set_event_log(dnas_model* m, int on) {
+  if (!m) return dnas::fail(DNAS_E_INVALID, "null model");
+  m->eventLog = on != 0;
+  return DNAS_OK;
+}
+
+// The traceback events of read `read_index` of the last call, in the order the traceback met them.
+extern "C" int dnas_model_read_events(dnas_model* m, int64_t read_index, uint64_t* out, int64_t cap, int64_t* n_events) {
+  if (!m || !n_events || read_index < 0) return dnas::fail(DNAS_E_INVALID, "dnas_model_read_events: bad argument");
+  *n_events = 0;
+  if (!m->dEvents || (size_t)read_index + 1 >= m->evOff.size()) return dnas::fail(DNAS_E_INVALID, "no event log for that read (dnas_model_set_event_log before the call)");
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipStreamSynchronize(m->stream2));
+  uint32_t n = 0;
+  HIP_TRY(hipMemcpy(&n, m->dEvLen + read_index, sizeof n, hipMemcpyDeviceToHost));
+  *n_events = n;
+  if (out && cap > 0) {
+    const size_t take = (size_t)std::min<int64_t>(cap, n);
+    if (take) HIP_TRY(hipMemcpy(out, m->dEvents + m->evOff[(size_t)read_index], take * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  }
+  return DNAS_OK;
+}
 
 // Tier C: compile the cluster kernel for a machine ahead of time (members = 0: the smallest cluster that fits).
 extern "C" int dnas_tierc_precompile(const dnas_flat_model* fm, int32_t members, char* note, size_t note_cap) {

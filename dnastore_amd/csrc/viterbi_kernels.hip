@@ -260,7 +260,8 @@ viterbi_traceback_kernel(DevModel m, const uint8_t* __restrict__ bases, const ui
                          const int32_t* __restrict__ batchRead, const uint64_t* __restrict__ slotOff,
                          const double* __restrict__ arena, char* __restrict__ outSym,
                          const uint64_t* __restrict__ outOff, uint32_t* __restrict__ outLen,
-                         uint8_t* __restrict__ outStatus, int nBatch) {
+                         uint8_t* __restrict__ outStatus, int nBatch,
+                         unsigned long long* __restrict__ events, const uint64_t* __restrict__ evOff, uint32_t* __restrict__ evLen) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nBatch) return;
   const int read = batchRead[b];
@@ -271,6 +272,15 @@ viterbi_traceback_kernel(DevModel m, const uint8_t* __restrict__ bases, const ui
   char* out = outSym + outOff[read];
   const long cap = (long)(outOff[read + 1] - outOff[read]);
   long n = 0;
+  // optional log of what the traceback found (the reference's level-3 messages, viterbi.cpp:266-293), in the order
+  // it walks (from the end of the read): type << 62 | pos << 32 | payload.  1 substitution at pos: emitted base << 2 |
+  // read base; 2 deletion between pos-1 and pos: the deleted base; 3 duplication at pos: count << 16 | bases (2 bits each)
+  unsigned long long* ev = events ? events + evOff[read] : nullptr;
+  const long evCap = events ? (long)(evOff[read + 1] - evOff[read]) : 0;
+  long nEv = 0;
+  bool bestEmit = false;     // the winning candidate is an emit in-edge (the reference's bestIts with a defined base)
+  uint8_t bestBase = 0;
+#define EVENT(type, p, payload) { if (nEv < evCap) ev[nEv] = ((unsigned long long)(type) << 62) | ((unsigned long long)(unsigned)(p) << 32) | (unsigned long long)(payload); ++nEv; }
 
 #define CELL(st, ps, ln) lattice_cell(m, lat, seq, (st), (ps), (ln))
   if (!(CELL(N - 1, L, 0) > kNegInf)) {  // viterbi.cpp:198-201
@@ -292,15 +302,17 @@ viterbi_traceback_kernel(DevModel m, const uint8_t* __restrict__ bases, const ui
   constexpr int CH = 4;
   int cSt[CH], cSlot[CH], cPs[CH], cLn[CH];
   double cTr[CH];
-  uint8_t cIn[CH];
-#define INIT_BEST() { best = kNegInf; found = false; bestIn = 0; }
+  uint8_t cIn[CH], cEm[CH];   // cEm: 0 not an emit in-edge, else 1 + emitted base
+#define INIT_BEST() { best = kNegInf; found = false; bestIn = 0; bestEmit = false; }
 #define FLUSH(cnt) { \
     double v_[CH]; \
     _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) v_[i_] = i_ < (cnt) ? cell_at(m, lat, seq, cSt[i_], cSlot[i_], cPs[i_], cLn[i_]) : kNegInf; \
     _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) if (i_ < (cnt)) { \
       const double sc_ = v_[i_] + cTr[i_]; \
-      if (sc_ > best) { best = sc_; bestCell = v_[i_]; bestState = cSt[i_]; bestPos = cPs[i_]; bestMut = cLn[i_]; bestIn = cIn[i_]; found = true; } } }
-#define SET(i, st_, slot_, ps_, ln_, tr_, in_) { cSt[i] = (st_); cSlot[i] = (slot_); cPs[i] = (ps_); cLn[i] = (ln_); cTr[i] = (tr_); cIn[i] = (in_); }
+      if (sc_ > best) { best = sc_; bestCell = v_[i_]; bestState = cSt[i_]; bestPos = cPs[i_]; bestMut = cLn[i_]; bestIn = cIn[i_]; found = true; \
+                        bestEmit = cEm[i_] != 0; bestBase = (uint8_t)(cEm[i_] - 1); } } }
+#define SET(i, st_, slot_, ps_, ln_, tr_, in_) { cSt[i] = (st_); cSlot[i] = (slot_); cPs[i] = (ps_); cLn[i] = (ln_); cTr[i] = (tr_); cIn[i] = (in_); cEm[i] = 0; }
+#define SET_EMIT(i, st_, slot_, ps_, ln_, tr_, in_, base_) { SET(i, st_, slot_, ps_, ln_, tr_, in_) cEm[i] = (uint8_t)(1 + (base_)); }
 #define CHECK_BEST() { \
     const double den_ = fabs(curCell) < 1e-6 ? 1. : curCell; \
     if (!(fabs((best - curCell) / den_) < 1e-6) || !found) { status = 3; break; } \
@@ -333,7 +345,7 @@ viterbi_traceback_kernel(DevModel m, const uint8_t* __restrict__ bases, const ui
           const int e1 = m.einPtr[state + 1];
           for (int e0 = m.einPtr[state]; e0 < e1; e0 += CH) {
             _Pragma("unroll") for (int i = 0; i < CH; ++i) if (e0 + i < e1)
-              SET(i, m.einSrc[e0 + i], m.einSlot[e0 + i], pos - 1, 0, (m.einScore[e0 + i] + m.noGap) + m.sub[m.einBase[e0 + i] * 4 + x], m.einIn[e0 + i])
+              SET_EMIT(i, m.einSrc[e0 + i], m.einSlot[e0 + i], pos - 1, 0, (m.einScore[e0 + i] + m.noGap) + m.sub[m.einBase[e0 + i] * 4 + x], m.einIn[e0 + i], m.einBase[e0 + i])
             FLUSH(e1 - e0 < CH ? e1 - e0 : CH)
           }
         }
@@ -354,12 +366,13 @@ viterbi_traceback_kernel(DevModel m, const uint8_t* __restrict__ bases, const ui
           ++c;
         }
         FLUSH(c)
+        if (ev && bestEmit && bestPos < pos && seq[pos - 1] != bestBase) EVENT(1, pos - 1, (bestBase << 2) | seq[pos - 1])   // viterbi.cpp:266-267
       } else if (mut == 1) {
         const int e1 = m.einPtr[state + 1];
         for (int e0 = m.einPtr[state]; e0 < e1; e0 += CH / 2) {
           _Pragma("unroll") for (int i = 0; i < CH / 2; ++i) if (e0 + i < e1) {
-            SET(2 * i, m.einSrc[e0 + i], m.einSlot[e0 + i], pos, 1, m.einScore[e0 + i] + m.delExtend, m.einIn[e0 + i])
-            SET(2 * i + 1, m.einSrc[e0 + i], m.einSlot[e0 + i], pos, 0, m.einScore[e0 + i] + m.delOpen, m.einIn[e0 + i])
+            SET_EMIT(2 * i, m.einSrc[e0 + i], m.einSlot[e0 + i], pos, 1, m.einScore[e0 + i] + m.delExtend, m.einIn[e0 + i], m.einBase[e0 + i])
+            SET_EMIT(2 * i + 1, m.einSrc[e0 + i], m.einSlot[e0 + i], pos, 0, m.einScore[e0 + i] + m.delOpen, m.einIn[e0 + i], m.einBase[e0 + i])
           }
           FLUSH(2 * (e1 - e0 < CH / 2 ? e1 - e0 : CH / 2))
         }
@@ -369,6 +382,8 @@ viterbi_traceback_kernel(DevModel m, const uint8_t* __restrict__ bases, const ui
             SET(i, m.ninSrc[e0 + i], m.ninSlot[e0 + i], pos, 1, m.ninScore[e0 + i], m.ninIn[e0 + i])
           FLUSH(n1 - e0 < CH ? n1 - e0 : CH)
         }
+        // viterbi.cpp:278-279 (for a null in-edge the reference prints an uninitialised base: not reproduced)
+        if (ev && bestEmit) EVENT(2, pos, bestBase)
       } else {
         const int k = mut - 2;
         int c = 0;
@@ -376,6 +391,11 @@ viterbi_traceback_kernel(DevModel m, const uint8_t* __restrict__ bases, const ui
         if (c == 0) SET(0, state, ownSlot, pos, 0, m.tanDup + m.len[k], 0) else SET(1, state, ownSlot, pos, 0, m.tanDup + m.len[k], 0)
         ++c;
         FLUSH(c)
+        if (ev && bestMut == 0) {        // viterbi.cpp:288-293: the duplicated bases, outermost first
+          unsigned bases = 0;
+          for (int q = k; q >= 0; --q) bases = (bases << 2) | ctx[q];
+          EVENT(3, pos, ((unsigned)(k + 1) << 16) | bases)
+        }
       }
       CHECK_BEST();
       if (bestIn) {  // trace.push_front (viterbi.cpp:299-300): fill the slot from its end
@@ -390,7 +410,10 @@ viterbi_traceback_kernel(DevModel m, const uint8_t* __restrict__ bases, const ui
 #undef SET
 #undef SLOT
 #undef CHECK_BEST
+#undef SET_EMIT
+#undef EVENT
 
+  if (evLen) evLen[read] = (uint32_t)(nEv < evCap ? nEv : evCap);
   if (status == 0 && n > cap) status = 2;  // DNAS_READ_OUT_OVERFLOW
   if (status != 0) {
     outLen[read] = 0;

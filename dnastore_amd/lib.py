@@ -117,6 +117,13 @@ def lib():
         "dnas_mutator_params_json": (ctypes.c_int, [P(MutatorParamsC), ctypes.c_char_p, sz]),
         "dnas_mutator_counts_json": (ctypes.c_int, [vp, ctypes.c_int32, ctypes.c_char_p, sz]),
         "dnas_decode_fastseqs": (ctypes.c_int, [cp, vp, P(MutatorParamsC), ctypes.c_int, P(vp)]),
+        "dnas_decode_fastseqs_ex": (ctypes.c_int, [cp, vp, P(MutatorParamsC), ctypes.c_int, ctypes.c_int, P(vp)]),
+        "dnas_decoded_tier": (cp, [vp]),
+        "dnas_decoded_devices": (ctypes.c_int, [vp]),
+        "dnas_decoded_events": (i64, [vp, i64, P(vp)]),
+        "dnas_device_count": (ctypes.c_int, []),
+        "dnas_model_set_event_log": (ctypes.c_int, [vp, ctypes.c_int]),
+        "dnas_model_read_events": (ctypes.c_int, [vp, i64, vp, i64, vp]),
         "dnas_decoded_count": (i64, [vp]),
         "dnas_decoded_name": (cp, [vp, i64]),
         "dnas_decoded_seq": (cp, [vp, i64]),

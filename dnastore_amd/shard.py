@@ -60,23 +60,42 @@ def scatter_reads(read_offsets, bases, world, rank, device):
 
 
 def gather_results(sym, out_len, loglike, status, world, rank):
-    """Fixed-shape per-rank result tensors (sym uint8[k*cap], out_len/loglike/status [k]) ->
-    on rank 0 a list over ranks of the same tuples (None elsewhere).  Equal k on every rank."""
+    """Per-rank result tensors (sym uint8[k*cap], out_len/loglike/status [k]) -> on rank 0 a list over ranks of
+    the same tuples (None elsewhere).  The ranks may hold different numbers of reads k (a job of n reads dealt
+    over W ranks gives n // W or n // W + 1 each): the buffers are padded to the largest shard for the gather and
+    cut back on rank 0.  The output capacity per read (cap) must be the same on every rank."""
     if not _dist_ready(world):
         return [(sym, out_len, loglike, status)]
-    # a gather of unequal shapes would hang or corrupt: check once, loudly
-    shape = torch.tensor([sym.numel(), -sym.numel(), out_len.numel(), -out_len.numel()], dtype=torch.int64, device=sym.device)
+    k = int(out_len.numel())
+    cap = sym.numel() // k if k else 0
+    shape = torch.tensor([k, cap, -cap if k else -(1 << 40)], dtype=torch.int64, device=sym.device)
     dist.all_reduce(shape, op=dist.ReduceOp.MAX)
-    if int(shape[0]) != -int(shape[1]) or int(shape[2]) != -int(shape[3]):
-        raise ValueError("gather_results: result buffers differ in size across ranks (use one output capacity and read count)")
+    kmax, capmax, capmin = int(shape[0]), int(shape[1]), -int(shape[2])
+    if k and (cap != capmax or capmin != capmax):
+        raise ValueError("gather_results: the output capacity per read differs across ranks")
+    cap = capmax
+
+    def padded(t, n):
+        if t.numel() == n:
+            return t
+        out = torch.zeros(n, dtype=t.dtype, device=t.device)
+        out[:t.numel()] = t
+        return out
+    ks = [torch.zeros(1, dtype=torch.int64, device=sym.device) for _ in range(world)] if rank == 0 else None
+    dist.gather(torch.tensor([k], dtype=torch.int64, device=sym.device), gather_list=ks, dst=0)
     outs = []
-    for t in (sym, out_len, loglike, status):
+    for t, n in ((sym, kmax * cap), (out_len, kmax), (loglike, kmax), (status, kmax)):
+        t = padded(t, n)
         bucket = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
         dist.gather(t, gather_list=bucket, dst=0)
         outs.append(bucket)
     if rank != 0:
         return None
-    return [tuple(outs[f][r] for f in range(4)) for r in range(world)]
+    res = []
+    for r in range(world):
+        kr = int(ks[r])
+        res.append((outs[0][r][:kr * cap], outs[1][r][:kr], outs[2][r][:kr], outs[3][r][:kr]))
+    return res
 
 
 def shard_pairs(pk, world, rank):

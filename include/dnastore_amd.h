@@ -161,6 +161,10 @@ int dnas_model_sync(dnas_model *model);
 /* Which fill kernel serves this model: "tier A: <shape>" (register/LDS-resident kernel, JIT-specialised
  * for the machine) or "tier B: <reason>" (general global-memory kernel).  DNAS_TIER=B forces tier B. */
 const char *dnas_model_tier(const dnas_model *model);
+/* Keep the traceback's event log (see dnas_decode_fastseqs_ex) for the following calls; dnas_model_read_events
+ * returns the events of read `read_index` of the last call (out may be NULL to ask for the count). */
+int dnas_model_set_event_log(dnas_model *model, int on);
+int dnas_model_read_events(dnas_model *model, int64_t read_index, uint64_t *out, int64_t cap, int64_t *n_events);
 /* Specialise + compile the tier-A kernel for a machine ahead of time (no GPU needed). */
 int dnas_tiera_precompile(const dnas_flat_model *fm, char *note, size_t note_cap);
 
@@ -257,9 +261,23 @@ int dnas_mutator_counts_json(const double *counts, int32_t n_len, char *buf, siz
 /* ---- convenience: the whole reference call ------------------------------------------ */
 
 typedef struct dnas_decoded dnas_decoded; /* vguard<FastSeq> result of decodeFastSeqs */
-/* decodeFastSeqs(filename, machine, params) (viterbi.cpp:306-320) on GPU `device_id`. */
+/* decodeFastSeqs(filename, machine, params) (viterbi.cpp:306-320) on GPU `device_id`; device_id = -1: on every GPU of
+ * the node -- the reads of the file are dealt over the devices (by length, snake order), one host thread and one
+ * model per device, results in file order: the serial loop of viterbi.cpp:312-318 has no dependence between reads.
+ * dnas_decode_fastseqs_ex with want_events != 0 also keeps what the traceback found (the reference's level-3 log
+ * messages, viterbi.cpp:266-293): per read a list of 64-bit events in the order the traceback met them,
+ * type << 62 | position << 32 | payload -- 1: substitution at position, payload = emitted base << 2 | read base;
+ * 2: deletion between position-1 and position, payload = the deleted base; 3: duplication at position, payload =
+ * count << 16 | the duplicated bases, 2 bits each, first one in the highest bits. */
 int dnas_decode_fastseqs(const char *fasta_path, const dnas_machine *m, const dnas_mutator_params *p,
                          int device_id, dnas_decoded **out);
+int dnas_decode_fastseqs_ex(const char *fasta_path, const dnas_machine *m, const dnas_mutator_params *p,
+                            int device_id, int want_events, dnas_decoded **out);
+const char *dnas_decoded_tier(const dnas_decoded *d);   /* which fill kernel served the machine ("tier A: ...") */
+int dnas_decoded_devices(const dnas_decoded *d);         /* how many devices shared the reads */
+int64_t dnas_decoded_events(const dnas_decoded *d, int64_t i, const uint64_t **events);
+/* GPUs visible to the library. */
+int dnas_device_count(void);
 int64_t dnas_decoded_count(const dnas_decoded *d);
 const char *dnas_decoded_name(const dnas_decoded *d, int64_t i);
 const char *dnas_decoded_seq(const dnas_decoded *d, int64_t i);

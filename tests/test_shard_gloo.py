@@ -80,25 +80,38 @@ def test_partition_balances_counts_and_lengths():
     assert abs(int(lens[parts[0]].sum()) - int(lens[parts[1]].sum())) <= int(lens.max()) // 2
 
 
-@pytest.mark.parametrize("world", [2])
-def test_scatter_decode_gather_matches_single_process(world):
-    n = 24
+def test_bench_reads_are_made_per_rank_by_index(ref_data):
+    """bench.py: every rank makes its own reads by index -- the shards of W ranks are the reads of one rank of a
+    W-times-larger job, read for read (no scatter needed to agree on the workload)."""
+    import bench
+    import dnastore_amd as da
+    m = da.Machine.fromFile(bench.MACHINE)
+    whole = bench.make_reads(m, 0, 12)
+    parts = [bench.make_reads(m, r * 3, 3) for r in range(4)]
+    assert [x for p in parts for x in p] == whole
+    assert len(set(whole)) == 12
+
+
+@pytest.mark.parametrize("world,n", [(2, 24), (8, 45)])      # 45 reads over 8 ranks: shards of 5 and 6 reads
+def test_scatter_decode_gather_matches_single_process(world, n):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
     for p in procs:
         p.start()
-    gathered, idx_list = q.get(timeout=120)
+    gathered, idx_list = q.get(timeout=240)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     off_all, bases_all = _reads(n, 7)
     cap = 48
     ref_sym, ref_len, ref_ll, ref_st = _fake_decode(off_all, bases_all, cap)
     seen = set()
+    assert sorted(len(x) for x in idx_list) == sorted([n // world + (1 if r < n % world else 0) for r in range(world)])
     for r in range(world):
         sym, olen, ll, st = gathered[r]
+        assert len(olen) == len(idx_list[r]) and len(sym) == len(idx_list[r]) * cap
         for j, i in enumerate(idx_list[r]):
             seen.add(i)
             assert olen[j] == ref_len[i] and ll[j] == ref_ll[i] and st[j] == ref_st[i]
