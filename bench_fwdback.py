@@ -1,0 +1,183 @@
+"""bench.py --config 4: the forward-backward E-step (expectedCounts, reference src/fwdback.cpp:190-209) over synthetic
+(original, read) pairs -- BASELINE configs[4], SURVEY 8(d) "Config 5": originals of 256 random nt, reads with tandem
+duplications (length 1-3, rate .01), substitutions (.02) and deletions (.01), the true alignment as the guide, the CLI
+default error model (P = 6).  125 000 pairs per GPU by default (1M over 8 GPUs); `--unique` distinct synthetic pairs
+are tiled to that number (making a million alignments in Python would take longer than the measurement).
+
+A "step" is one E-step over the shard with the database resident in HBM (dnas_fb handle: table and pairs uploaded
+once); `value` = read (output) nt per second.  The DP cells live on chip, so HBM only sees inputs and outputs: the
+roofline object reports the bound the kernel is actually under -- the fp64 log-sum-exp rate -- beside the HBM figure.
+With N > 1 ranks every rank makes its own pairs; the 22+P counts are all-reduced (RCCL) inside the timed region.
+"""
+import json
+import os
+import random
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0
+
+
+def make_pairs(O, first, count, unique):
+    from synth import synthetic_alignment
+    uniq = []
+    for u in range(min(unique, count)):
+        rng = random.Random(50000 + (first + u) % unique)
+        uniq.append(O.alignment_pair(synthetic_alignment(rng, 256, sub=.02, dele=.01, dup=.01)))
+    return [uniq[i % len(uniq)] for i in range(count)]
+
+
+def _cpu_worker(job):
+    pairs, = job
+    from oracle import oracle as O
+    t0 = time.perf_counter()
+    res = O.expected_counts(O.MutatorParams.from_cli(), pairs)
+    return time.perf_counter() - t0, res
+
+
+def main(args):
+    import torch
+    import torch.distributed as dist
+    import dnastore_amd as da
+    from dnastore_amd import shard
+    from oracle import oracle as O          # pair packing + CPU baseline (checker code, outside the timed region)
+    import bench
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    backend = os.environ.get("DNAS_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    coll_device = device if backend == "nccl" else torch.device("cpu")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+
+    n_pairs = args.reads or 125000
+    unique = 2000
+    pairs = make_pairs(O, rank * n_pairs, n_pairs, unique)
+    pk = O.pack_pairs(pairs)
+    nt = int(pk["out_off"][-1])
+    params = da.MutatorParams.fromFlags()
+    fb = da.ForwardBackward(pk, device=local_rank)
+
+    def step():
+        counts, ll, _ = fb.expectedCounts(params, want_pair_ll=False)
+        return shard.allreduce_counts(counts, ll, world, coll_device)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    kernel_ms, lse_ops = 0.0, 0
+    res = None
+    for _ in range(args.steps):
+        res = step()
+        st = fb.stats()
+        kernel_ms += st["kernel_ms"]
+        lse_ops += st["lse_ops"]
+    fence()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed, float(nt), float(n_pairs)], dtype=torch.float64, device=coll_device)
+    if world > 1:
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed, total_nt, total_pairs = float(tmax[0]), float(tsum[1]), float(tsum[2])
+    else:
+        total_nt, total_pairs = float(nt), float(n_pairs)
+
+    if rank == 0:
+        st = fb.stats()
+        cpu, extra = None, {}
+        if world == 1:
+            # the same shard through the one-call entry point (host arrays in, counts out: table + database uploaded per call)
+            tp = time.perf_counter()
+            c1, ll1, per1 = da.expectedCounts(params, pk, device=local_rank)
+            extra["value_pcie_inclusive"] = nt / (time.perf_counter() - tp)
+            if args.cpu_seconds > 0:
+                import multiprocessing as mp
+                O.build()
+                oparams = O.MutatorParams.from_cli()
+                t1 = time.perf_counter()
+                n1 = 0
+                while time.perf_counter() - t1 < args.cpu_seconds / 3.0 and n1 < n_pairs:
+                    O.expected_counts(oparams, pairs[n1:n1 + 50])
+                    n1 += 50
+                dt1 = time.perf_counter() - t1
+                nt1 = int(sum(len(p[1]) for p in pairs[:n1]))
+                rate1 = nt1 / dt1
+                cores = bench.host_cores()
+                per_core = max(50, int(args.cpu_seconds * (n1 / dt1)))
+                jobs = [(pairs[(c * per_core) % max(n_pairs - per_core, 1):][:per_core],) for c in range(cores)]
+                ctx = mp.get_context("spawn")
+                with ctx.Pool(len(jobs)) as pool:
+                    pool.map(_cpu_worker, [(j[0][:2],) for j in jobs])
+                    t2 = time.perf_counter()
+                    parts = pool.map(_cpu_worker, jobs)
+                    wall = time.perf_counter() - t2
+                ntc = int(sum(len(p[1]) for j in jobs for p in j[0]))
+                cpu = dict(value=ntc / wall, unit="nt/s", cores=len(jobs), kind="port", value_one_core=rate1,
+                           sample="%d pairs (%d nt) over %d processes (one per host core), oracle/fwdback_oracle.c, %.1f s wall; one core alone: %.0f nt/s"
+                                  % (sum(len(j[0]) for j in jobs), ntc, len(jobs), wall, rate1))
+                # parity: per-pair log-likelihoods bit for bit, counts to 1e-9, on a sample
+                m = min(300, n_pairs)
+                oc, oll, oper = O.expected_counts(oparams, pairs[:m])
+                if not np.array_equal(per1[:m], oper):
+                    raise SystemExit("PARITY FAILURE: per-pair log-likelihoods differ from the oracle")
+                gc, gll, _ = da.expectedCounts(params, O.pack_pairs(pairs[:m]), device=local_rank)
+                if not np.allclose(gc, oc, rtol=1e-9, atol=1e-300):
+                    raise SystemExit("PARITY FAILURE: counts differ from the oracle")
+                cpu["parity_checked_pairs"] = m
+        value = total_nt * args.steps / elapsed
+        # algorithmic HBM bytes per pair: the two sequences (1 B/nt), the guide columns (4 B per position) and
+        # the 22+P doubles that come back
+        P = len(params.pLen)
+        in_nt = int(pk["in_off"][-1])
+        alg_bytes = (in_nt + nt) + 4 * (in_nt + nt + 2 * n_pairs) + 8 * (22 + P) * n_pairs
+        line = {
+            "metric": "forward-backward E-step, read nt/sec (whole node)",
+            "value": value, "unit": "nt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[4]: %d pairs/GPU of a 256-nt original and its read (dup .01, sub .02, del .01), guide = true alignment, "
+                                   "CLI default model (P = 6), %d distinct pairs tiled" % (n_pairs, min(unique, n_pairs)),
+                       "pairs_per_gpu": n_pairs, "total_nt": int(total_nt), "parallelism": "pair-sharded x%d, counts all-reduced" % world},
+            "pairs_per_s": total_pairs * args.steps / elapsed,
+            "roofline": {"bound": "hbm", "achieved": alg_bytes * args.steps / (kernel_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg_bytes * args.steps / (kernel_ms / 1e3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
+                         "kernel": "fwdback_onchip_kernel", "avg_launch_ms": kernel_ms / args.steps,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "the DP cells live in LDS: the kernel is bound by the dependent log-sum-exp look-ups of a cell, not by HBM; "
+                                 "lse_ops_per_s is its real rate",
+                         "lse_ops_per_s": lse_ops / (kernel_ms / 1e3) if kernel_ms > 0 else 0.0,
+                         "pairs_onchip": st["pairs_onchip"], "pairs_streaming": st["pairs_streaming"]},
+            "cpu_baseline": cpu,
+        }
+        line.update(extra)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    fb.close()

@@ -5,7 +5,8 @@ written gfx950 HIP kernels); this package is the thin Python mirror of the refer
 operator surface used by tests and bench.py: Machine (src/trans.h), MutatorParams
 (src/mutator.h) and decodeFastSeqs / ViterbiMatrix (src/viterbi.h:94-108).
 """
-from .api import (FlatModel, Machine, MutatorParams, StockholmDB, ViterbiDecoder, baumWelchParams, countsJSON,  # noqa: F401
+from .api import (FlatModel, ForwardBackward, Machine, MutatorParams, StockholmDB, ViterbiDecoder, baumWelchParams, countsJSON,  # noqa: F401
                   decode_fastseqs, expectedCounts, paramsJSON, symbolsToBytes,
                   pack_reads, read_fastseqs, tokenize)
+from . import lib  # noqa: F401
 from .lib import DnasError, LIB_PATH  # noqa: F401

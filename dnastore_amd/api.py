@@ -366,6 +366,40 @@ def _pair_ptrs(pk):
     return keep, [a.ctypes.data for a in keep]
 
 
+class ForwardBackward:
+    """A database of alignment pairs resident on one GPU (dnas_fb): load once, run the E-step many times."""
+
+    def __init__(self, pairs, device=0):
+        self._h = ctypes.c_void_p()
+        _l.check(_l.lib().dnas_fb_create(int(device), ctypes.byref(self._h)))
+        pk = pairs.arrays() if isinstance(pairs, StockholmDB) else pairs
+        keep, ptrs = _pair_ptrs(pk)
+        self.n = int(pk["n"])
+        _l.check(_l.lib().dnas_fb_load_pairs(self._h, self.n, *ptrs))
+
+    def expectedCounts(self, params, strict=False, want_pair_ll=True):
+        """-> (counts float64[21+P], ll, per-pair ll float64[n] or None)."""
+        counts = np.zeros(21 + params.c.n_len)
+        ll = ctypes.c_double()
+        per = np.zeros(max(self.n, 1)) if want_pair_ll else None
+        _l.check(_l.lib().dnas_fb_estep(self._h, ctypes.byref(params.c), int(bool(strict)), counts.ctypes.data, ctypes.addressof(ll),
+                                        per.ctypes.data if want_pair_ll else None))
+        return counts, ll.value, (per[:self.n] if want_pair_ll else None)
+
+    def stats(self):
+        s = _l.FbStatsC()
+        _l.check(_l.lib().dnas_fb_last_stats(self._h, ctypes.byref(s)))
+        return {k: getattr(s, k) for k, _ in s._fields_}
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _l.lib().dnas_fb_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        self.close()
+
+
 def expectedCounts(params, pairs, strict=False, device=0):
     """expectedCounts(params, db, ll, strict) (fwdback.cpp:190-209) on the GPU.
     pairs: StockholmDB or a dict of packed arrays (ins, in_off, outs, out_off, cm_in, cm_in_off, cm_out, cm_out_off, n).

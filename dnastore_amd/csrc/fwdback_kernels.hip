@@ -2,6 +2,9 @@
 // counts() (reference src/fwdback.cpp:43-188) and the per-alignment loop of expectedCounts
 // (fwdback.cpp:190-209).
 //
+// This is the STREAMING kernel, the fallback for pairs the on-chip kernel (fwdback_onchip.hip) does not take: an
+// envelope row wider than 16 cells, or more than 8 duplication lengths.
+//
 // One THREAD per alignment pair (the DP of one pair is a short banded scan with almost no
 // internal parallelism: ~2P+1 cells per row; a database holds 10^5..10^6 independent pairs).
 // The banded Forward matrix of a batch lives in HBM interleaved across the batch,
@@ -52,14 +55,14 @@ fwdback_estep_kernel(FbArgs a, const int8_t* __restrict__ inSeqs, const int64_t*
                      const int32_t* __restrict__ cmOut, const int64_t* __restrict__ cmOutOff,
                      const double* __restrict__ lseTab, double* __restrict__ fwd, double* __restrict__ rows,
                      double* __restrict__ pairCounts, double* __restrict__ pairLL, int64_t first, int nBatch,
-                     int64_t cellCap) {
+                     int64_t cellCap, const int64_t* __restrict__ pairList) {
   __shared__ double subS[16], lenS[kFbMaxLen];
   if (threadIdx.x < 16) subS[threadIdx.x] = a.sub[threadIdx.x];
   if (threadIdx.x < kFbMaxLen) lenS[threadIdx.x] = a.len[threadIdx.x];
   __syncthreads();
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nBatch) return;
-  const int64_t pair = first + b;
+  const int64_t pair = pairList ? pairList[first + b] : first + b;
   const int P = a.P, W = P + 2;
   const size_t B = (size_t)nBatch;
   const int8_t* in = inSeqs + inOff[pair];

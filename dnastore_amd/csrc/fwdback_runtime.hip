@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -17,7 +18,10 @@
 
 extern "C" __global__ void fwdback_estep_kernel(FbArgs, const int8_t*, const int64_t*, const int8_t*, const int64_t*,
                                                 const int32_t*, const int64_t*, const int32_t*, const int64_t*,
-                                                const double*, double*, double*, double*, double*, int64_t, int, int64_t);
+                                                const double*, double*, double*, double*, double*, int64_t, int, int64_t, const int64_t*);
+extern "C" __global__ void fwdback_onchip_kernel(FbArgs, const int8_t*, const int64_t*, const int8_t*, const int64_t*,
+                                                 const int32_t*, const int64_t*, const int32_t*, const int64_t*,
+                                                 const double*, const int64_t*, int64_t, double*, double*, int, unsigned long long*);
 extern "C" __global__ void fwdback_reduce_kernel(const double*, const double*, int64_t, int, double*);
 
 #define HIP_TRY(expr)                                                                          \
@@ -48,23 +52,154 @@ bool isTransition(int x, int y) { return x != y && (x & 1) == (y & 1); }
 
 }  // namespace
 
-extern "C" int dnas_fwdback_estep(const dnas_mutator_params* p, int strict, int64_t n_pairs, const int8_t* in_seqs,
-                                  const int64_t* in_off, const int8_t* out_seqs, const int64_t* out_off,
-                                  const int32_t* cm_in, const int64_t* cm_in_off, const int32_t* cm_out,
-                                  const int64_t* cm_out_off, int device_id, double* out_counts, double* out_ll,
-                                  double* out_pair_ll) {
+// ---- the persistent handle ---------------------------------------------------------------------------
+// What is per device (the log-sum-exp table, a stream), what is per database (the pairs, their envelope widths per
+// guide mode, the result buffers) and what is per E-step (the scores) are uploaded / computed once each; an EM run
+// calls dnas_fb_estep up to 100 times on the same handle.
+struct dnas_fb {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double* dTab = nullptr;
+  // database
+  int64_t nPairs = 0;
+  int P = -1;                    // pLen size the per-pair buffers are sized for
+  int maxInLen = 0;
+  std::vector<int64_t> inOff, outOff, ciOff, coOff;          // host copies (envelope census)
+  std::vector<int32_t> ci, co;
+  int8_t *dIn = nullptr, *dOut = nullptr;
+  int64_t *dInOff = nullptr, *dOutOff = nullptr, *dCiOff = nullptr, *dCoOff = nullptr;
+  int32_t *dCi = nullptr, *dCo = nullptr;
+  double *dCounts = nullptr, *dLL = nullptr, *dPartial = nullptr;
+  unsigned long long* dLseOps = nullptr;
+  // per guide mode (0: the envelope is maxDistance = P wide, 1: strict) and P: which kernel takes which pair
+  struct Route { int P = -1; std::vector<int64_t> onchip, streaming; std::vector<int64_t> cells; std::vector<int> width;
+                 int64_t* dOnchip = nullptr; int64_t* dStreaming = nullptr; };
+  Route route[2];
+  // streaming kernel arenas
+  double *dFwd = nullptr, *dRows = nullptr;
+  size_t fwdBytes = 0, rowsBytes = 0;
+  dnas_fb_stats stats{};
+};
+
+namespace {
+
+void fbFreeDatabase(dnas_fb* h) {
+  for (void* q : {(void*)h->dIn, (void*)h->dOut, (void*)h->dInOff, (void*)h->dOutOff, (void*)h->dCiOff, (void*)h->dCoOff, (void*)h->dCi,
+                  (void*)h->dCo, (void*)h->dCounts, (void*)h->dLL, (void*)h->dPartial})
+    if (q) (void)hipFree(q);
+  h->dIn = h->dOut = nullptr; h->dInOff = h->dOutOff = h->dCiOff = h->dCoOff = nullptr; h->dCi = h->dCo = nullptr;
+  h->dCounts = h->dLL = h->dPartial = nullptr;
+  for (auto& r : h->route) {
+    if (r.dOnchip) (void)hipFree(r.dOnchip);
+    if (r.dStreaming) (void)hipFree(r.dStreaming);
+    r = dnas_fb::Route{};
+  }
+  h->nPairs = 0; h->P = -1;
+}
+
+}  // namespace
+
+extern "C" int dnas_fb_create(int device_id, dnas_fb** out) {
   auto cleanup = [] {};
-  if (!p || n_pairs < 0 || !out_counts || !out_ll) return dnas::fail(DNAS_E_INVALID, "dnas_fwdback_estep: null argument");
+  if (!out) return dnas::fail(DNAS_E_INVALID, "dnas_fb_create: null argument");
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return dnas::fail(DNAS_E_DEVICE, "no HIP device available");
+  if (device_id < 0 || device_id >= count) return dnas::fail(DNAS_E_INVALID, "device_id out of range");
+  HIP_TRY(hipSetDevice(device_id));
+  dnas_fb* h = new dnas_fb();
+  h->device = device_id;
+  auto cleanup2 = [&] { dnas_fb_destroy(h); };
+#define cleanup cleanup2
+  HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreate(&h->ev0));
+  HIP_TRY(hipEventCreate(&h->ev1));
+  const std::vector<double>& tab = lseTable();
+  HIP_TRY(hipMalloc((void**)&h->dTab, tab.size() * sizeof(double)));
+  HIP_TRY(hipMemcpy(h->dTab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc((void**)&h->dLseOps, sizeof(unsigned long long)));
+#undef cleanup
+  *out = h;
+  return DNAS_OK;
+}
+
+extern "C" void dnas_fb_destroy(dnas_fb* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  fbFreeDatabase(h);
+  for (void* q : {(void*)h->dTab, (void*)h->dFwd, (void*)h->dRows, (void*)h->dLseOps})
+    if (q) (void)hipFree(q);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+extern "C" int dnas_fb_load_pairs(dnas_fb* h, int64_t n_pairs, const int8_t* in_seqs, const int64_t* in_off, const int8_t* out_seqs,
+                                  const int64_t* out_off, const int32_t* cm_in, const int64_t* cm_in_off, const int32_t* cm_out,
+                                  const int64_t* cm_out_off) {
+  auto cleanup = [] {};
+  if (!h || n_pairs < 0) return dnas::fail(DNAS_E_INVALID, "dnas_fb_load_pairs: bad argument");
+  if (n_pairs > 0 && (!in_seqs || !in_off || !out_seqs || !out_off || !cm_in || !cm_in_off || !cm_out || !cm_out_off))
+    return dnas::fail(DNAS_E_INVALID, "dnas_fb_load_pairs: null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  fbFreeDatabase(h);
+  if (n_pairs == 0) return DNAS_OK;
+  // ---- validate (the kernels trust these)
+  int maxIn = 0;
+  for (int64_t i = 0; i < n_pairs; ++i) {
+    const int64_t inLen = in_off[i + 1] - in_off[i], outLen = out_off[i + 1] - out_off[i];
+    if (inLen < 0 || outLen < 0 || cm_in_off[i + 1] - cm_in_off[i] != inLen + 1 || cm_out_off[i + 1] - cm_out_off[i] != outLen + 1)
+      return dnas::fail(DNAS_E_INVALID, "pair " + std::to_string(i) + ": inconsistent offsets");
+    if (inLen > 30000 || outLen > 30000) return dnas::fail(DNAS_E_UNSUPPORTED, "pair " + std::to_string(i) + ": sequences longer than 30000");
+    const int32_t* ci = cm_in + cm_in_off[i];
+    const int32_t* co = cm_out + cm_out_off[i];
+    for (int64_t k = 0; k < inLen; ++k) if (in_seqs[in_off[i] + k] < 0 || in_seqs[in_off[i] + k] > 3) return dnas::fail(DNAS_E_BAD_BASE, "bad base");
+    for (int64_t k = 0; k < outLen; ++k) if (out_seqs[out_off[i] + k] < 0 || out_seqs[out_off[i] + k] > 3) return dnas::fail(DNAS_E_BAD_BASE, "bad base");
+    for (int64_t k = 0; k < inLen; ++k) if (ci[k + 1] < ci[k]) return dnas::fail(DNAS_E_INVALID, "cm_in must be non-decreasing");
+    for (int64_t k = 0; k < outLen; ++k) if (co[k + 1] < co[k]) return dnas::fail(DNAS_E_INVALID, "cm_out must be non-decreasing");
+    maxIn = std::max<int>(maxIn, (int)inLen);
+  }
+  auto cleanup2 = [&] { fbFreeDatabase(h); };
+#define cleanup cleanup2
+  const size_t nIn = (size_t)in_off[n_pairs], nOut = (size_t)out_off[n_pairs];
+  const size_t nCi = (size_t)cm_in_off[n_pairs], nCo = (size_t)cm_out_off[n_pairs];
+#define UPLOAD(dst, src, n, T)                                                     \
+  HIP_TRY(hipMalloc((void**)&dst, std::max<size_t>((n), 1) * sizeof(T)));         \
+  if (n) HIP_TRY(hipMemcpy(dst, src, (n) * sizeof(T), hipMemcpyHostToDevice));
+  UPLOAD(h->dIn, in_seqs, nIn, int8_t) UPLOAD(h->dOut, out_seqs, nOut, int8_t)
+  UPLOAD(h->dInOff, in_off, (size_t)n_pairs + 1, int64_t) UPLOAD(h->dOutOff, out_off, (size_t)n_pairs + 1, int64_t)
+  UPLOAD(h->dCi, cm_in, nCi, int32_t) UPLOAD(h->dCo, cm_out, nCo, int32_t)
+  UPLOAD(h->dCiOff, cm_in_off, (size_t)n_pairs + 1, int64_t) UPLOAD(h->dCoOff, cm_out_off, (size_t)n_pairs + 1, int64_t)
+#undef UPLOAD
+  HIP_TRY(hipMalloc((void**)&h->dLL, (size_t)n_pairs * sizeof(double)));
+#undef cleanup
+  h->nPairs = n_pairs;
+  h->maxInLen = maxIn;
+  h->inOff.assign(in_off, in_off + n_pairs + 1);
+  h->outOff.assign(out_off, out_off + n_pairs + 1);
+  h->ciOff.assign(cm_in_off, cm_in_off + n_pairs + 1);
+  h->coOff.assign(cm_out_off, cm_out_off + n_pairs + 1);
+  h->ci.assign(cm_in, cm_in + nCi);
+  h->co.assign(cm_out, cm_out + nCo);
+  return DNAS_OK;
+}
+
+extern "C" int dnas_fb_estep(dnas_fb* h, const dnas_mutator_params* p, int strict, double* out_counts, double* out_ll,
+                             double* out_pair_ll) {
+  auto cleanup = [] {};
+  if (!h || !p || !out_counts || !out_ll) return dnas::fail(DNAS_E_INVALID, "dnas_fb_estep: null argument");
   const int P = p->n_len, nc = 21 + P;
   if (P < 0 || P > kFbMaxLen) return dnas::fail(DNAS_E_UNSUPPORTED, "pLen longer than 32 entries");
   for (int k = 0; k < nc; ++k) out_counts[k] = 0;
   *out_ll = 0;
+  h->stats = dnas_fb_stats{};
+  const int64_t n_pairs = h->nPairs;
   if (n_pairs == 0) return DNAS_OK;
-  if (!in_seqs || !in_off || !out_seqs || !out_off || !cm_in || !cm_in_off || !cm_out || !cm_out_off)
-    return dnas::fail(DNAS_E_INVALID, "dnas_fwdback_estep: null argument");
-  int count = 0;
-  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return dnas::fail(DNAS_E_DEVICE, "no HIP device available");
-  if (device_id < 0 || device_id >= count) return dnas::fail(DNAS_E_INVALID, "device_id out of range");
+  HIP_TRY(hipSetDevice(h->device));
 
   // ---- scores (MutatorScores, mutator.cpp:56-75)
   FbArgs a{};
@@ -81,112 +216,150 @@ extern "C" int dnas_fwdback_estep(const dnas_mutator_params* p, int strict, int6
       a.sub[i * 4 + j] = (i == j ? std::log(pMatch) : (isTransition(i, j) ? std::log(p->p_transition) : std::log(p->p_transversion / 2))) - nullScore;
   for (int k = 0; k < P; ++k) a.len[k] = std::log(p->p_len[k]);
 
-  // ---- per-pair envelope sizes (cells, widest row); validates the inputs
-  const int Dm = a.maxDistance;
-  std::vector<int64_t> cells((size_t)n_pairs);
-  std::vector<int> width((size_t)n_pairs);
-  for (int64_t i = 0; i < n_pairs; ++i) {
-    const int64_t inLen = in_off[i + 1] - in_off[i], outLen = out_off[i + 1] - out_off[i];
-    if (inLen < 0 || outLen < 0 || cm_in_off[i + 1] - cm_in_off[i] != inLen + 1 || cm_out_off[i + 1] - cm_out_off[i] != outLen + 1)
-      return dnas::fail(DNAS_E_INVALID, "pair " + std::to_string(i) + ": inconsistent offsets");
-    const int32_t* ci = cm_in + cm_in_off[i];
-    const int32_t* co = cm_out + cm_out_off[i];
-    for (int64_t k = 0; k < inLen; ++k) if (in_seqs[in_off[i] + k] < 0 || in_seqs[in_off[i] + k] > 3) return dnas::fail(DNAS_E_BAD_BASE, "bad base");
-    for (int64_t k = 0; k < outLen; ++k) if (out_seqs[out_off[i] + k] < 0 || out_seqs[out_off[i] + k] > 3) return dnas::fail(DNAS_E_BAD_BASE, "bad base");
-    for (int64_t k = 0; k < inLen; ++k) if (ci[k + 1] < ci[k]) return dnas::fail(DNAS_E_INVALID, "cm_in must be non-decreasing");
-    for (int64_t k = 0; k < outLen; ++k) if (co[k + 1] < co[k]) return dnas::fail(DNAS_E_INVALID, "cm_out must be non-decreasing");
-    int64_t lo = 0, hi = -1, tot = 0;
-    int w = 1;
-    for (int64_t ip = 0; ip <= inLen; ++ip) {
-      while (lo <= outLen && co[lo] < ci[ip] - Dm) ++lo;
-      if (hi < lo - 1) hi = lo - 1;
-      while (hi + 1 <= outLen && co[hi + 1] <= ci[ip] + Dm) ++hi;
-      tot += hi - lo + 1;
-      w = std::max<int>(w, (int)(hi - lo + 1));
+  // ---- which kernel takes which pair: the on-chip kernel serves envelope rows of up to 16 cells and up to 8
+  // duplication lengths; the census depends on the envelope half-width (P, or 0 with strict guides) and is kept
+  dnas_fb::Route& rt = h->route[strict ? 1 : 0];
+  if (rt.P != P) {
+    if (rt.dOnchip) { (void)hipFree(rt.dOnchip); rt.dOnchip = nullptr; }
+    if (rt.dStreaming) { (void)hipFree(rt.dStreaming); rt.dStreaming = nullptr; }
+    rt.onchip.clear(); rt.streaming.clear();
+    rt.cells.assign((size_t)n_pairs, 1);
+    rt.width.assign((size_t)n_pairs, 1);
+    const int Dm = a.maxDistance;
+    const bool forceStreaming = getenv("DNAS_FB_STREAMING") != nullptr;
+    for (int64_t i = 0; i < n_pairs; ++i) {
+      const int64_t inLen = h->inOff[i + 1] - h->inOff[i], outLen = h->outOff[i + 1] - h->outOff[i];
+      const int32_t* ci = h->ci.data() + h->ciOff[i];
+      const int32_t* co = h->co.data() + h->coOff[i];
+      int64_t lo = 0, hi = -1, tot = 0;
+      int w = 1;
+      for (int64_t ip = 0; ip <= inLen; ++ip) {
+        while (lo <= outLen && co[lo] < ci[ip] - Dm) ++lo;
+        if (hi < lo - 1) hi = lo - 1;
+        while (hi + 1 <= outLen && co[hi + 1] <= ci[ip] + Dm) ++hi;
+        tot += hi - lo + 1;
+        w = std::max<int>(w, (int)(hi - lo + 1));
+      }
+      rt.cells[(size_t)i] = std::max<int64_t>(tot, 1);
+      rt.width[(size_t)i] = w;
+      (w <= kFbLanes && P <= 8 && !forceStreaming ? rt.onchip : rt.streaming).push_back(i);
     }
-    cells[i] = std::max<int64_t>(tot, 1);
-    width[i] = w;
+    auto put = [&](const std::vector<int64_t>& v, int64_t** d) -> hipError_t {
+      hipError_t e = hipMalloc((void**)d, std::max<size_t>(v.size(), 1) * sizeof(int64_t));
+      if (e == hipSuccess && !v.empty()) e = hipMemcpy(*d, v.data(), v.size() * sizeof(int64_t), hipMemcpyHostToDevice);
+      return e;
+    };
+    HIP_TRY(put(rt.onchip, &rt.dOnchip));
+    HIP_TRY(put(rt.streaming, &rt.dStreaming));
+    rt.P = P;
   }
+  if (h->P != P) {   // result buffers are sized by the number of counts
+    if (h->dCounts) { (void)hipFree(h->dCounts); h->dCounts = nullptr; }
+    if (h->dPartial) { (void)hipFree(h->dPartial); h->dPartial = nullptr; }
+    HIP_TRY(hipMalloc((void**)&h->dCounts, (size_t)n_pairs * nc * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&h->dPartial, (size_t)256 * (nc + 1) * sizeof(double)));
+    h->P = P;
+  }
+  HIP_TRY(hipMemsetAsync(h->dLseOps, 0, sizeof(unsigned long long), h->stream));
+  HIP_TRY(hipEventRecord(h->ev0, h->stream));
 
-  HIP_TRY(hipSetDevice(device_id));
-  const size_t W = (size_t)P + 2;
-  int8_t *dIn = nullptr, *dOut = nullptr;
-  int64_t *dInOff = nullptr, *dOutOff = nullptr, *dCiOff = nullptr, *dCoOff = nullptr;
-  int32_t *dCi = nullptr, *dCo = nullptr;
-  double *dTab = nullptr, *dFwd = nullptr, *dRows = nullptr, *dCounts = nullptr, *dLL = nullptr, *dPartial = nullptr;
-  auto cleanup2 = [&] {
-    for (void* q : {(void*)dIn, (void*)dOut, (void*)dInOff, (void*)dOutOff, (void*)dCiOff, (void*)dCoOff, (void*)dCi, (void*)dCo,
-                    (void*)dTab, (void*)dFwd, (void*)dRows, (void*)dCounts, (void*)dLL, (void*)dPartial})
-      if (q) (void)hipFree(q);
-  };
-#define cleanup cleanup2
-  const size_t nIn = (size_t)in_off[n_pairs], nOut = (size_t)out_off[n_pairs];
-  const size_t nCi = (size_t)cm_in_off[n_pairs], nCo = (size_t)cm_out_off[n_pairs];
-  const std::vector<double>& tab = lseTable();
-#define UPLOAD(dst, src, n, T)                                                     \
-  HIP_TRY(hipMalloc((void**)&dst, std::max<size_t>((n), 1) * sizeof(T)));         \
-  if (n) HIP_TRY(hipMemcpy(dst, src, (n) * sizeof(T), hipMemcpyHostToDevice));
-  UPLOAD(dIn, in_seqs, nIn, int8_t) UPLOAD(dOut, out_seqs, nOut, int8_t)
-  UPLOAD(dInOff, in_off, (size_t)n_pairs + 1, int64_t) UPLOAD(dOutOff, out_off, (size_t)n_pairs + 1, int64_t)
-  UPLOAD(dCi, cm_in, nCi, int32_t) UPLOAD(dCo, cm_out, nCo, int32_t)
-  UPLOAD(dCiOff, cm_in_off, (size_t)n_pairs + 1, int64_t) UPLOAD(dCoOff, cm_out_off, (size_t)n_pairs + 1, int64_t)
-  UPLOAD(dTab, tab.data(), tab.size(), double)
-#undef UPLOAD
-  HIP_TRY(hipMalloc((void**)&dCounts, (size_t)n_pairs * nc * sizeof(double)));
-  HIP_TRY(hipMalloc((void**)&dLL, (size_t)n_pairs * sizeof(double)));
-
-  // ---- batches: the interleaved Forward arena holds cellCap cells for each of B pairs
-  size_t freeB = 0, totalB = 0;
-  HIP_TRY(hipMemGetInfo(&freeB, &totalB));
-  const size_t budget = std::min<size_t>((size_t)((double)freeB * 0.5), (size_t)16 << 30);
-  int64_t start = 0;
-  size_t arenaBytes = 0, rowsBytes = 0;
-  while (start < n_pairs) {
-    // grow the batch while it fits the budget
-    int64_t end = start, cap = 0;
-    int rowCap = 1;
-    while (end < n_pairs && end - start < (1 << 16)) {
-      const int64_t c2 = std::max(cap, cells[end]);
-      const int r2 = std::max(rowCap, width[end]);
-      const size_t need = ((size_t)c2 + 2 * (size_t)r2) * W * sizeof(double) * (size_t)(end - start + 1);
-      if (need > budget && end > start) break;
-      cap = c2; rowCap = r2; ++end;
-    }
-    const int nB = (int)(end - start);
-    const size_t fwdNeed = (size_t)cap * W * sizeof(double) * nB, rowNeed = 2 * (size_t)rowCap * W * sizeof(double) * nB;
-    if (fwdNeed > arenaBytes) {
-      if (dFwd) { (void)hipFree(dFwd); dFwd = nullptr; }
-      HIP_TRY(hipMalloc((void**)&dFwd, fwdNeed));
-      arenaBytes = fwdNeed;
-    }
-    if (rowNeed > rowsBytes) {
-      if (dRows) { (void)hipFree(dRows); dRows = nullptr; }
-      HIP_TRY(hipMalloc((void**)&dRows, rowNeed));
-      rowsBytes = rowNeed;
-    }
-    a.rowCap = rowCap;
-    hipLaunchKernelGGL(fwdback_estep_kernel, dim3((nB + kFbThreads - 1) / kFbThreads), dim3(kFbThreads), 0, 0, a, dIn, dInOff,
-                       dOut, dOutOff, dCi, dCiOff, dCo, dCoOff, dTab, dFwd, dRows, dCounts, dLL, start, nB, cap);
+  // ---- on-chip kernel: two pairs per work-group, everything in LDS
+  if (!rt.onchip.empty()) {
+    const size_t lds = kFbPairsPerGroup * fbOnchipPairDoubles(h->maxInLen) * sizeof(double);
+    if (lds > 150 * 1024) return dnas::fail(DNAS_E_UNSUPPORTED, "sequences too long for the on-chip forward-backward kernel");
+    const int64_t nL = (int64_t)rt.onchip.size();
+    hipLaunchKernelGGL(fwdback_onchip_kernel, dim3((unsigned)((nL + kFbPairsPerGroup - 1) / kFbPairsPerGroup)), dim3(kFbLanes * kFbPairsPerGroup),
+                       lds, h->stream, a, h->dIn, h->dInOff, h->dOut, h->dOutOff, h->dCi, h->dCiOff, h->dCo, h->dCoOff, h->dTab, rt.dOnchip, nL,
+                       h->dCounts, h->dLL, h->maxInLen, h->dLseOps);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
-    start = end;
   }
+  // ---- streaming kernel for the rest: the interleaved Forward arena holds cellCap cells for each of B pairs
+  if (!rt.streaming.empty()) {
+    const size_t W = (size_t)P + 2;
+    size_t freeB = 0, totalB = 0;
+    HIP_TRY(hipMemGetInfo(&freeB, &totalB));
+    const size_t budget = std::max<size_t>(h->fwdBytes + h->rowsBytes, std::min<size_t>((size_t)((double)freeB * 0.5), (size_t)16 << 30));
+    const int64_t nS = (int64_t)rt.streaming.size();
+    int64_t start = 0;
+    while (start < nS) {
+      int64_t end = start, cap = 0;
+      int rowCap = 1;
+      while (end < nS && end - start < (1 << 16)) {
+        const int64_t c2 = std::max(cap, rt.cells[(size_t)rt.streaming[(size_t)end]]);
+        const int r2 = std::max(rowCap, rt.width[(size_t)rt.streaming[(size_t)end]]);
+        const size_t need = ((size_t)c2 + 2 * (size_t)r2) * W * sizeof(double) * (size_t)(end - start + 1);
+        if (need > budget && end > start) break;
+        cap = c2; rowCap = r2; ++end;
+      }
+      const int nB = (int)(end - start);
+      const size_t fwdNeed = (size_t)cap * W * sizeof(double) * nB, rowNeed = 2 * (size_t)rowCap * W * sizeof(double) * nB;
+      if (fwdNeed > h->fwdBytes) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (h->dFwd) { (void)hipFree(h->dFwd); h->dFwd = nullptr; h->fwdBytes = 0; }
+        HIP_TRY(hipMalloc((void**)&h->dFwd, fwdNeed));
+        h->fwdBytes = fwdNeed;
+      }
+      if (rowNeed > h->rowsBytes) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (h->dRows) { (void)hipFree(h->dRows); h->dRows = nullptr; h->rowsBytes = 0; }
+        HIP_TRY(hipMalloc((void**)&h->dRows, rowNeed));
+        h->rowsBytes = rowNeed;
+      }
+      a.rowCap = rowCap;
+      hipLaunchKernelGGL(fwdback_estep_kernel, dim3((nB + kFbThreads - 1) / kFbThreads), dim3(kFbThreads), 0, h->stream, a, h->dIn, h->dInOff,
+                         h->dOut, h->dOutOff, h->dCi, h->dCiOff, h->dCo, h->dCoOff, h->dTab, h->dFwd, h->dRows, h->dCounts, h->dLL, start, nB, cap,
+                         (const int64_t*)rt.dStreaming);
+      HIP_TRY(hipGetLastError());
+      start = end;     // (the next batch reuses the arenas: same stream, in order)
+    }
+  }
+  HIP_TRY(hipEventRecord(h->ev1, h->stream));
 
   // ---- reduction over pairs: fixed-shape tree, block partials added in order on the host
   const int nBlocks = (int)std::min<int64_t>(256, (n_pairs + 255) / 256);
-  HIP_TRY(hipMalloc((void**)&dPartial, (size_t)nBlocks * (nc + 1) * sizeof(double)));
-  hipLaunchKernelGGL(fwdback_reduce_kernel, dim3(nBlocks), dim3(256), 0, 0, dCounts, dLL, n_pairs, nc, dPartial);
+  hipLaunchKernelGGL(fwdback_reduce_kernel, dim3(nBlocks), dim3(256), 0, h->stream, h->dCounts, h->dLL, n_pairs, nc, h->dPartial);
   HIP_TRY(hipGetLastError());
   std::vector<double> partial((size_t)nBlocks * (nc + 1));
-  HIP_TRY(hipMemcpy(partial.data(), dPartial, partial.size() * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpyAsync(partial.data(), h->dPartial, partial.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (out_pair_ll) HIP_TRY(hipMemcpyAsync(out_pair_ll, h->dLL, (size_t)n_pairs * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  unsigned long long ops = 0;
+  HIP_TRY(hipMemcpyAsync(&ops, h->dLseOps, sizeof ops, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
   for (int b = 0; b < nBlocks; ++b) {
     for (int k = 0; k < nc; ++k) out_counts[k] += partial[(size_t)b * (nc + 1) + k];
     *out_ll += partial[(size_t)b * (nc + 1) + nc];
   }
-  if (out_pair_ll) HIP_TRY(hipMemcpy(out_pair_ll, dLL, (size_t)n_pairs * sizeof(double), hipMemcpyDeviceToHost));
-  cleanup();
-#undef cleanup
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  h->stats.kernel_ms = ms;
+  h->stats.pairs_onchip = (int64_t)rt.onchip.size();
+  h->stats.pairs_streaming = (int64_t)rt.streaming.size();
+  h->stats.lse_ops = (int64_t)ops;
+  int64_t ntOut = 0;
+  for (int64_t i = 0; i < n_pairs; ++i) ntOut += h->outOff[i + 1] - h->outOff[i];
+  h->stats.out_nt = ntOut;
   return DNAS_OK;
+}
+
+extern "C" int dnas_fb_last_stats(const dnas_fb* h, dnas_fb_stats* out) {
+  if (!h || !out) return dnas::fail(DNAS_E_INVALID, "null argument");
+  *out = h->stats;
+  return DNAS_OK;
+}
+
+// expectedCounts in one call (host pointers in, counts out): a handle for the length of the call
+extern "C" int dnas_fwdback_estep(const dnas_mutator_params* p, int strict, int64_t n_pairs, const int8_t* in_seqs,
+                                  const int64_t* in_off, const int8_t* out_seqs, const int64_t* out_off,
+                                  const int32_t* cm_in, const int64_t* cm_in_off, const int32_t* cm_out,
+                                  const int64_t* cm_out_off, int device_id, double* out_counts, double* out_ll,
+                                  double* out_pair_ll) {
+  if (!p || n_pairs < 0 || !out_counts || !out_ll) return dnas::fail(DNAS_E_INVALID, "dnas_fwdback_estep: null argument");
+  dnas_fb* h = nullptr;
+  int rc = dnas_fb_create(device_id, &h);
+  if (rc == DNAS_OK) rc = dnas_fb_load_pairs(h, n_pairs, in_seqs, in_off, out_seqs, out_off, cm_in, cm_in_off, cm_out, cm_out_off);
+  if (rc == DNAS_OK) rc = dnas_fb_estep(h, p, strict, out_counts, out_ll, out_pair_ll);
+  dnas_fb_destroy(h);
+  return rc;
 }
 
 // ---- Baum-Welch driver (host): the EM loop around the GPU E-step -------------------------------
@@ -231,14 +404,18 @@ extern "C" int dnas_baum_welch(const dnas_mutator_params* init, int strict, int6
   if (!init || !out) return dnas::fail(DNAS_E_INVALID, "dnas_baum_welch: null argument");
   dnas_mutator_params cur = *init;
   const int P = cur.n_len, nc = 21 + P;
+  // one handle for the whole EM run: the database and the log-sum-exp table go to the GPU once
+  dnas_fb* h = nullptr;
+  int rc0 = dnas_fb_create(device_id, &h);
+  if (rc0 == DNAS_OK) rc0 = dnas_fb_load_pairs(h, n_pairs, in_seqs, in_off, out_seqs, out_off, cm_in, cm_in_off, cm_out, cm_out_off);
+  if (rc0 != DNAS_OK) { dnas_fb_destroy(h); return rc0; }
   std::vector<double> counts(nc), prior(nc, 1.);          // prior.initLaplace(), dnastore.cpp:137-138
   double best = -INFINITY;
   int iter = 0;
   for (; iter < 100; ++iter) {                            // BaumWelchMaxIter, fwdback.cpp:8
     double ll = 0;
-    const int rc = dnas_fwdback_estep(&cur, strict, n_pairs, in_seqs, in_off, out_seqs, out_off, cm_in, cm_in_off, cm_out,
-                                      cm_out_off, device_id, counts.data(), &ll, nullptr);
-    if (rc != DNAS_OK) return rc;
+    const int rc = dnas_fb_estep(h, &cur, strict, counts.data(), &ll, nullptr);
+    if (rc != DNAS_OK) { dnas_fb_destroy(h); return rc; }
     ll += logPrior(prior.data(), cur);
     if ((ll - best) / std::fabs(best) < .001) break;      // BaumWelchMinFracInc, fwdback.cpp:7,221
     best = ll;
@@ -253,6 +430,7 @@ extern "C" int dnas_baum_welch(const dnas_mutator_params* init, int strict, int6
     cur.p_transversion = nv / (ni + nv + nm);
     cur.local = init->local;
   }
+  dnas_fb_destroy(h);
   *out = cur;
   if (out_iterations) *out_iterations = iter;
   return DNAS_OK;

@@ -52,6 +52,11 @@ class PairsViewC(ctypes.Structure):
                 ("cm_in_off", ctypes.c_void_p), ("cm_out", ctypes.c_void_p), ("cm_out_off", ctypes.c_void_p)]
 
 
+class FbStatsC(ctypes.Structure):
+    _fields_ = [("kernel_ms", ctypes.c_double), ("pairs_onchip", ctypes.c_int64), ("pairs_streaming", ctypes.c_int64),
+                ("lse_ops", ctypes.c_int64), ("out_nt", ctypes.c_int64)]
+
+
 class BatchStatsC(ctypes.Structure):
     _fields_ = [("fill_ms", ctypes.c_double), ("traceback_ms", ctypes.c_double), ("fill_launches", ctypes.c_int64),
                 ("columns", ctypes.c_int64), ("lattice_bytes", ctypes.c_int64), ("rounds", ctypes.c_int64)]
@@ -110,6 +115,11 @@ def lib():
         "dnas_model_last_stats": (ctypes.c_int, [vp, P(BatchStatsC)]),
         "dnas_model_read_lattice": (ctypes.c_int, [vp, i64, i64, vp]),
         "dnas_fwdback_estep": (ctypes.c_int, [P(MutatorParamsC), ctypes.c_int, i64] + [vp] * 8 + [ctypes.c_int, vp, vp, vp]),
+        "dnas_fb_create": (ctypes.c_int, [ctypes.c_int, P(vp)]),
+        "dnas_fb_load_pairs": (ctypes.c_int, [vp, i64] + [vp] * 8),
+        "dnas_fb_estep": (ctypes.c_int, [vp, P(MutatorParamsC), ctypes.c_int, vp, vp, vp]),
+        "dnas_fb_last_stats": (ctypes.c_int, [vp, P(FbStatsC)]),
+        "dnas_fb_destroy": (None, [vp]),
         "dnas_baum_welch": (ctypes.c_int, [P(MutatorParamsC), ctypes.c_int, i64] + [vp] * 8 + [ctypes.c_int, P(MutatorParamsC), vp]),
         "dnas_stockholm_read": (ctypes.c_int, [cp, P(vp)]),
         "dnas_pairs_get": (P(PairsViewC), [vp]),

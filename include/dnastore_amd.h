@@ -230,6 +230,27 @@ int dnas_fwdback_estep(const dnas_mutator_params *params, int strict, int64_t n_
                        const int64_t *cm_in_off, const int32_t *cm_out, const int64_t *cm_out_off, int device_id,
                        double *out_counts, double *out_ll, double *out_pair_ll);
 
+/* The same E-step behind a persistent handle: the log-sum-exp table (per device) and the database (per load) go to
+ * the GPU once; dnas_fb_estep then runs on the handle's own stream with buffers it keeps -- the EM loop calls it up
+ * to 100 times.  Pairs whose envelope rows are at most 16 cells wide (and n_len <= 8) are served by the on-chip
+ * kernel (nothing of the DP matrices touches HBM); the rest by the streaming kernel.  dnas_fwdback_estep and
+ * dnas_baum_welch are built on this. */
+typedef struct dnas_fb dnas_fb;
+typedef struct dnas_fb_stats {
+  double kernel_ms;                 /* E-step kernels of the last call (HIP events on the handle's stream) */
+  int64_t pairs_onchip, pairs_streaming;
+  int64_t lse_ops;                  /* log_sum_exp evaluations of the on-chip kernel (counted in the kernel) */
+  int64_t out_nt;                   /* sum of the read (output) lengths */
+} dnas_fb_stats;
+int dnas_fb_create(int device_id, dnas_fb **out);
+int dnas_fb_load_pairs(dnas_fb *h, int64_t n_pairs, const int8_t *in_seqs, const int64_t *in_off, const int8_t *out_seqs,
+                       const int64_t *out_off, const int32_t *cm_in, const int64_t *cm_in_off, const int32_t *cm_out,
+                       const int64_t *cm_out_off);
+int dnas_fb_estep(dnas_fb *h, const dnas_mutator_params *params, int strict, double *out_counts, double *out_ll,
+                  double *out_pair_ll);
+int dnas_fb_last_stats(const dnas_fb *h, dnas_fb_stats *out);
+void dnas_fb_destroy(dnas_fb *h);
+
 /* baumWelchParams(init, Laplace prior, db, strict) (fwdback.cpp:211-230, dnastore.cpp:135-140):
  * EM on the host around the GPU E-step; at most 100 iterations, stops when the relative gain
  * of log(likelihood * prior) drops below 1e-3. */
