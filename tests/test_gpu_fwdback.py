@@ -80,3 +80,40 @@ def test_empty_database(da):
         cm_in=np.zeros(0, np.int32), cm_in_off=np.zeros(1, np.int64), cm_out=np.zeros(0, np.int32),
         cm_out_off=np.zeros(1, np.int64), n=0))
     assert not counts.any() and ll == 0 and len(per) == 0
+
+
+def test_onchip_and_streaming_kernels_agree(oracle_mod, monkeypatch):
+    """The persistent handle (dnas_fb): the on-chip kernel takes the pairs whose envelope rows are at most 16 cells
+    wide, the streaming kernel the rest; both reproduce the oracle's per-pair log-likelihoods bit for bit, agree
+    with each other on the counts, and a second E-step on the same handle (another model) reuses the database."""
+    import random
+    import dnastore_amd as da
+    from synth import synthetic_alignment
+    O = oracle_mod
+    rng = random.Random(21)
+    pairs = [O.alignment_pair(synthetic_alignment(rng, rng.choice([1, 7, 33, 100, 256]), sub=.03, dele=.02, dup=.02)) for _ in range(90)]
+    # a pair with a long run of duplications: envelope rows wider than 16 cells -> streaming kernel
+    pairs.append(O.alignment_pair(synthetic_alignment(random.Random(5), 60, sub=.02, dele=.0, dup=.35)))
+    pk = O.pack_pairs(pairs)
+    params = da.MutatorParams.fromFlags()
+    fb = da.ForwardBackward(pk)
+    counts, ll, per = fb.expectedCounts(params)
+    st = fb.stats()
+    assert st["pairs_onchip"] >= 60 and st["pairs_streaming"] >= 1 and st["pairs_onchip"] + st["pairs_streaming"] == len(pairs) and st["lse_ops"] > 0
+    oc, oll, oper = O.expected_counts(O.MutatorParams.from_cli(), pairs)
+    assert np.array_equal(per, oper)
+    assert np.allclose(counts, oc, rtol=1e-9, atol=1e-300)
+    # strict guides on the same handle: another envelope, another census
+    c2, ll2, per2 = fb.expectedCounts(params, strict=True)
+    oc2, oll2, oper2 = O.expected_counts(O.MutatorParams.from_cli(), pairs, strict=True)
+    assert np.array_equal(per2, oper2) and np.allclose(c2, oc2, rtol=1e-9, atol=1e-300)
+    # and the first model again: identical bits run to run
+    c3, ll3, per3 = fb.expectedCounts(params)
+    assert np.array_equal(c3, counts) and ll3 == ll and np.array_equal(per3, per)
+    fb.close()
+    monkeypatch.setenv("DNAS_FB_STREAMING", "1")
+    fb = da.ForwardBackward(pk)
+    cs, lls, pers = fb.expectedCounts(params)
+    assert fb.stats()["pairs_onchip"] == 0
+    assert np.array_equal(pers, per) and np.allclose(cs, counts, rtol=1e-11, atol=1e-300)
+    fb.close()
