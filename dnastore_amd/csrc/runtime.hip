@@ -1,6 +1,7 @@
 // Device runtime behind the C ABI: model upload, lattice arena, batch scheduling and
 // kernel launches for the Viterbi path (include/dnastore_amd.h, "device side").
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cctype>
@@ -20,6 +21,7 @@ extern "C" __global__ void viterbi_fill_kernel(DevModel, const uint8_t*, const u
                                                const uint64_t*, double*, double*, unsigned long long*, int);
 extern "C" __global__ void expand_lattice_kernel(DevModel, const uint8_t*, const double*, double*);
 extern "C" __global__ void fill_neginf_kernel(double*, size_t);
+extern "C" __global__ void check_bases_kernel(const uint8_t*, size_t, unsigned long long*);
 extern "C" __global__ void viterbi_traceback_kernel(DevModel, const uint8_t*, const uint64_t*, const int32_t*,
                                                     const uint64_t*, const double*, char*, const uint64_t*,
                                                     uint32_t*, uint8_t*, int, unsigned long long*, const uint64_t*, uint32_t*);
@@ -95,6 +97,7 @@ struct dnas_model {
   size_t halfDoubles = 0;              // size of one arena half (doubles)
   std::vector<uint64_t> lastSlotOff;   // host copy, sorted-batch order of the last call
   std::vector<int32_t> lastBatchRead;
+  std::vector<int64_t> lastBatchStart; // first read (sorted order) of every batch of the last call, + n_reads
   std::vector<uint64_t> lastReadOff;   // host copy of the last call's read offsets
   const uint8_t* lastBases = nullptr;  // device pointer of the last call's bases (valid while the caller keeps it)
   uint8_t* keepBases = nullptr;        // dnas_viterbi_batch's own copy, kept until the next call (lattice export)
@@ -110,6 +113,29 @@ struct dnas_model {
 };
 
 namespace {
+
+// roctx ranges around the phases of a call (visible in rocprofv3 --marker-trace): the marker library is looked up at run
+// time, so that the shared library does not depend on it
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    for (const char* lib : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+      if (void* h = dlopen(lib, RTLD_LAZY | RTLD_LOCAL)) {
+        push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+        pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (push && pop) return;
+        push = nullptr; pop = nullptr;
+      }
+    }
+  }
+};
+const Roctx& roctx() { static Roctx r; return r; }
+struct RoctxRange {
+  bool on;
+  explicit RoctxRange(const char* name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+  ~RoctxRange() { if (on) roctx().pop(); }
+};
 
 template <class T>
 int upload(dnas_model* m, const T* host, size_t n, const T** out) {
@@ -217,7 +243,7 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
   memcpy(d.sub, fm->sub, sizeof d.sub);
   for (int k = 0; k < kMaxLen; ++k) d.len[k] = k < fm->n_len ? fm->len[k] : 0.;
   d.slotOf = nullptr;
-  if (hipMalloc((void**)&m->dRounds, 8 * sizeof(unsigned long long)) != hipSuccess)
+  if (hipMalloc((void**)&m->dRounds, 16 * sizeof(unsigned long long)) != hipSuccess)
     return bail(dnas::fail(DNAS_E_DEVICE, "hipMalloc failed"));
   // ---- tier A: specialise the register/LDS-resident kernel for this machine
   auto uploadEdgeSlots = [&](const int32_t* slotOf) -> int {   // after the tier (and with it the slot map) is known
@@ -389,6 +415,8 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
   if (!m || n_reads < 0 || (n_reads > 0 && (!read_offsets || !d_bases || !d_out_sym || !out_offsets || !d_out_len ||
                                             !d_out_loglike || !d_out_status)))
     return dnas::fail(DNAS_E_INVALID, "dnas_viterbi_batch_device: bad argument");
+  RoctxRange callRange("dnas_viterbi_batch_device");
+  if (n_reads > 0x7fffffffll) return dnas::fail(DNAS_E_UNSUPPORTED, "more than 2^31-1 reads in one call");
   HIP_TRY(hipSetDevice(m->device));
   // the previous call's events/stat buffers are about to be reused
   HIP_TRY(hipStreamSynchronize(m->stream));
@@ -396,6 +424,20 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
   m->stats = dnas_batch_stats{};
   m->statsPending = false;
   if (n_reads == 0) return DNAS_OK;
+  {
+    // the kernels index their substitution tables with the base codes: anything but 0..3 must not reach them
+    const size_t nBases = (size_t)(read_offsets[n_reads] - read_offsets[0]);
+    if (nBases) {
+      HIP_TRY(hipMemsetAsync(m->dRounds + 8, 0, sizeof(unsigned long long), m->stream));
+      hipLaunchKernelGGL(check_bases_kernel, dim3((unsigned)std::min<size_t>((nBases + 255) / 256, 4096)), dim3(256), 0, m->stream,
+                         d_bases + read_offsets[0], nBases, m->dRounds + 8);
+      HIP_TRY(hipGetLastError());
+      unsigned long long bad = 0;
+      HIP_TRY(hipMemcpyAsync(&bad, m->dRounds + 8, sizeof bad, hipMemcpyDeviceToHost, m->stream));
+      HIP_TRY(hipStreamSynchronize(m->stream));
+      if (bad) return dnas::fail(DNAS_E_BAD_BASE, "base code > 3 in the device buffer (bases are 0..3 = ACGT)");
+    }
+  }
   const DevModel& d = m->dm;
   const size_t lanes = (size_t)d.D + 2;
   const size_t colDoubles = (size_t)d.storedLanes * (size_t)d.Npad;
@@ -432,6 +474,7 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
     columns += (int64_t)L + 1;
   }
   batchStart.push_back(n_reads);
+  m->lastBatchStart = batchStart;
   const bool pingPong = batchStart.size() > 2;          // more than one batch
   if ((pingPong ? 2 : 1) * peak * sizeof(double) > m->arenaBytes) {
     if (m->arena) HIP_TRY(hipFree(m->arena));
@@ -504,6 +547,7 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
     // the half this batch fills was last read by the traceback of batch b-2
     if (b >= 2) HIP_TRY(hipStreamWaitEvent(m->stream, m->sync[2 * (b - 2) + 1], 0));
     HIP_TRY(hipEventRecord(m->events[4 * b], m->stream));
+    { RoctxRange fillRange(m->tier == 2 ? "viterbi fill (tier C)" : (m->tier == 1 ? "viterbi fill (tier A)" : "viterbi fill (tier B)"));
     if (m->tier >= 1) {
       TierALaunch la{m->argsA, m->dEntTab, m->dMetaTab, d_bases, m->dReadOff, m->dBatchRead + s, m->dSlotOff + s,
                      m->arena, d_out_loglike, m->dRounds, nullptr, nullptr, nullptr, 0, nB, 0ull};
@@ -536,8 +580,10 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
                          (const uint64_t*)(m->dSlotOff + s), m->arena, d_out_loglike, m->dRounds, maskWords);
       HIP_TRY(hipGetLastError());
     }
+    }
     HIP_TRY(hipEventRecord(m->events[4 * b + 1], m->stream));
     HIP_TRY(hipEventRecord(m->sync[2 * b], m->stream));
+    RoctxRange tbRange("viterbi traceback");
     HIP_TRY(hipStreamWaitEvent(m->stream2, m->sync[2 * b], 0));
     HIP_TRY(hipEventRecord(m->events[4 * b + 2], m->stream2));
     hipLaunchKernelGGL(viterbi_traceback_kernel, dim3((nB + kTraceThreads - 1) / kTraceThreads), dim3(kTraceThreads), 0,
@@ -614,13 +660,22 @@ extern "C" int dnas_model_read_lattice(dnas_model* m, int64_t slot, int64_t len,
     return dnas::fail(DNAS_E_INVALID, "dnas_model_read_lattice: bad argument");
   HIP_TRY(hipSetDevice(m->device));
   HIP_TRY(hipStreamSynchronize(m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream2));
+  if (!m->lastBases) return dnas::fail(DNAS_E_INVALID, "dnas_model_read_lattice: the read bases of the last call are gone");
   const DevModel& d = m->dm;
   const size_t lanes = (size_t)d.D + 2;
-  // `slot` indexes the caller's read order; find its arena slot (valid for the last batch of the call)
+  // `slot` indexes the caller's read order; find its arena slot.  The arena has two halves that the batches of a call
+  // use in turn: only the lattices of the last two batches still exist.
   size_t pos = 0;
   for (; pos < m->lastBatchRead.size(); ++pos)
     if (m->lastBatchRead[pos] == (int32_t)slot) break;
-  if (pos == m->lastBatchRead.size()) return dnas::fail(DNAS_E_INVALID, "no such read in the last batch");
+  if (pos == m->lastBatchRead.size()) return dnas::fail(DNAS_E_INVALID, "no such read in the last call");
+  {
+    size_t batchOf = 0;
+    while (batchOf + 1 < m->lastBatchStart.size() && (int64_t)pos >= m->lastBatchStart[batchOf + 1]) ++batchOf;
+    const size_t nB = m->lastBatchStart.size() - 1;
+    if (batchOf + 2 < nB) return dnas::fail(DNAS_E_INVALID, "dnas_model_read_lattice: that read's lattice has been overwritten by a later batch of the call");
+  }
   if ((uint64_t)len != m->lastReadOff[slot + 1] - m->lastReadOff[slot]) return dnas::fail(DNAS_E_INVALID, "length mismatch");
   const size_t n = (size_t)(len + 1) * lanes * (size_t)d.N;
   double* dOut = nullptr;

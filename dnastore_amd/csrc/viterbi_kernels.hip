@@ -107,6 +107,13 @@ __device__ __forceinline__ double cell_at(const DevModel& m, const double* __res
 
 }  // namespace
 
+// Device-side guard of dnas_viterbi_batch_device: counts base codes outside 0..3.
+extern "C" __global__ void check_bases_kernel(const uint8_t* __restrict__ bases, size_t n, unsigned long long* __restrict__ bad) {
+  unsigned mine = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) mine += bases[i] > 3;
+  if (mine) atomicAdd(bad, (unsigned long long)mine);
+}
+
 // -inf into every cell of the tier-C exchange buffers before a launch.
 extern "C" __global__ void fill_neginf_kernel(double* __restrict__ p, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
