@@ -184,3 +184,33 @@ def test_device_pointer_entry_point_matches_host_entry_point(da, ref_data):
     assert got == want_sym
     assert np.array_equal(d_ll.cpu().numpy(), want_ll) and np.array_equal(d_st.cpu().numpy(), want_st)
     dec.close()
+
+
+def test_device_entry_point_rejects_bad_bases_and_stale_lattices(da, ref_data):
+    """dnas_viterbi_batch_device checks its inputs too (a base code > 3 would index past the kernels' tables), and
+    dnas_model_read_lattice refuses a read whose arena half a later batch of the call has reused."""
+    import torch
+    from dnastore_amd import lib as L
+    m = da.Machine.fromFile(os.path.join(ref_data, "l4c4.json"))
+    dec = da.ViterbiDecoder(m, da.MutatorParams.fromFlags(), options="max_slots=2")
+    reads = [m.encodeBytes(bytes([i])) for i in range(7)]           # 4 batches of at most 2 reads
+    out, ll, st = dec.decode(reads)
+    assert dec.stats()["fill_launches"] == 4
+    dec.lattice(6, len(reads[6]))                                   # last batch: fine
+    with pytest.raises(L.DnasError):
+        dec.lattice(0, len(reads[0]))                               # first batch: its half has been overwritten
+    off, bases = da.pack_reads(reads[:2])
+    bad = torch.from_numpy(bases.copy()).cuda()
+    bad[3] = 7
+    n = 2
+    cap = 256
+    ooff = np.arange(n + 1, dtype=np.uint64) * np.uint64(cap)
+    sym = torch.zeros(n * cap, dtype=torch.uint8, device="cuda")
+    olen = torch.zeros(n, dtype=torch.int32, device="cuda")
+    llt = torch.zeros(n, dtype=torch.float64, device="cuda")
+    stt = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    with pytest.raises(L.DnasError) as e:
+        dec.decode_device(off, bad.data_ptr(), sym.data_ptr(), ooff, olen.data_ptr(), llt.data_ptr(), stt.data_ptr())
+    assert "DNAS_E_BAD_BASE" in str(e.value)
+    dec.close()
