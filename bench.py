@@ -183,6 +183,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline time budget (0 = skip)")
     ap.add_argument("--arena-gb", type=float, default=0.0, help="lattice arena per GPU (0 = the library's default, 60 %% of free HBM)")
     ap.add_argument("--scatter", action="store_true", help="rank 0 makes every rank's reads and scatters them (RCCL) instead of per-rank generation")
+    ap.add_argument("--timed-only", action="store_true", help="skip the passes outside the timed region (PCIe-inclusive, single-read latency, CPU baseline): "
+                                                              "every launch of the run is then one of the timed steps (profiling)")
     ap.add_argument("--options", default=None, help='dnas_model_create_ex options, e.g. "max_slots=690"')
     args = ap.parse_args()
     if args.config == 4:
@@ -291,7 +293,7 @@ def main():
     if rank == 0:
         extra = {}
         cpu = None
-        if world == 1:
+        if world == 1 and not args.timed_only:
             # ---- the same shard through the host-pointer entry point (dnas_viterbi_batch): H2D of the reads, D2H of the
             # decoded strings, per-call device buffers -- SURVEY 8(d)'s PCIe-inclusive rate; never `value`
             dec.decode(my_reads[:min(k, 64)])

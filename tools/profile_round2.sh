@@ -13,7 +13,7 @@ rocprofv3 --kernel-trace --stats -d $OUT/trace -o run --output-format csv -- pyt
 if [ -z "$NO_PMC" ]; then
   for C in FETCH_SIZE WRITE_SIZE; do
     echo "== $NAME: pmc $C" >> $R/gpurun_out/prof2/progress.log
-    rocprofv3 --pmc $C -d $OUT/pmc_$C -o run --output-format csv -- python3 $R/bench.py "$@" --cpu-seconds 0 --steps 1 --warmup 0 > $OUT/pmc_${C}_bench.json 2> $OUT/pmc_$C.log || echo "pmc $C failed" >> $R/gpurun_out/prof2/progress.log
+    rocprofv3 --pmc $C -d $OUT/pmc_$C -o run --output-format csv -- python3 $R/bench.py "$@" --cpu-seconds 0 --timed-only --steps 1 --warmup 0 > $OUT/pmc_${C}_bench.json 2> $OUT/pmc_$C.log || echo "pmc $C failed" >> $R/gpurun_out/prof2/progress.log
   done
 fi
 find $OUT -name "*.csv" >> $R/gpurun_out/prof2/progress.log
