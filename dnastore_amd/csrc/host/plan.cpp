@@ -17,8 +17,9 @@ constexpr int kWalk = 30;         // length of the walks the sweep estimate look
 
 struct Edge { int src, dst, sc, base, isNull; };
 // out-edges, has null in-edges, not plain (some out-edge is a null edge or carries a score), score class of the
-// out-edges (4: they differ, 7: no out-edge) -- in a row's caps: the mask of classes it admits
-typedef std::array<int, 4> Type;
+// out-edges (4: they differ, 7: no out-edge) -- in a row's caps: the mask of classes it admits --, has an out-edge
+// into another member of the cluster (its entries are decoded per lane: kept to a few rows at the end of the program)
+typedef std::array<int, 5> Type;
 
 // Which member of the cluster owns which state.  The in-column recursion runs along the machine's chains, and every
 // edge between two members costs a trip through the exchange buffer (microseconds, against nanoseconds inside a CU):
@@ -154,7 +155,7 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G) {
 
   std::vector<Type> type(N);
   int maxOut = 0;
-  std::vector<int> nNullDestOf(G, 0);
+  std::vector<int> nNullDestOf(G, 0), remoteOutOf(G, 0), remoteOutSOf(G, 0);
   for (int j = 0; j < N; ++j) {
     int hasS = 0;
     for (int e : inOf[j]) hasS |= edges[e].isNull;
@@ -163,12 +164,26 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G) {
     if (outOf[j].empty()) notPlain = 1;   // would leave an empty entry in an otherwise full plain row
     int cls = 7;
     for (int e : outOf[j]) cls = cls == 7 ? edges[e].sc : (cls == edges[e].sc ? cls : 4);
-    type[j] = Type{(int)outOf[j].size(), hasS, notPlain, cls};
+    int remoteOut = 0;
+    for (int e : outOf[j]) remoteOut |= part[edges[e].dst] != part[j] ? 1 : 0;
+    type[j] = Type{(int)outOf[j].size(), hasS, notPlain, cls, remoteOut};
+    remoteOutOf[part[j]] += remoteOut;
+    remoteOutSOf[part[j]] += remoteOut && hasS;
     maxOut = std::max(maxOut, type[j][0]);
     nNullDestOf[part[j]] += hasS;
   }
-  int nNullDestMax = 0;
+  int nNullDestMax = 0, nRemoteRows = 0;
   for (int g = 0; g < G; ++g) nNullDestMax = std::max(nNullDestMax, nNullDestOf[g]);
+  // the states that offer into another member sit in the last rows of the program (they are where a member's chains
+  // end); the other rows keep the cheap all-LDS entry decode
+  int nRemoteSRows = 0;     // ... of which this many carry S cells (such a state may have null in-edges too)
+  for (int g = 0; g < G; ++g) {
+    const int withS = (remoteOutSOf[g] + T - 1) / T;
+    nRemoteSRows = std::max(nRemoteSRows, withS);
+    nRemoteRows = std::max(nRemoteRows, withS + (remoteOutOf[g] - remoteOutSOf[g] + T - 1) / T);
+  }
+  nRemoteRows = std::max(nRemoteRows, nRemoteSRows);
+  if (getenv("DNAS_PLAN_NO_REMOTE_ROWS")) nRemoteRows = nRemoteSRows = 0;
   if (getenv("DNAS_PLAN_DEBUG") && G > 1) {
     for (int g = 0; g < G; ++g)
       fprintf(stderr, "plan member %d: %zu states, %d fed by other members, %d with null in-edges\n", g, walkOf[g].size(), inboxCount[g], nNullDestOf[g]);
@@ -205,9 +220,13 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G) {
     std::vector<unsigned> admits(types.size(), 0), own(types.size(), 0);
     for (size_t t = 0; t < types.size(); ++t)
       for (int k = 0; k < K; ++k)
-        if (types[t][0] <= caps[k][0] && types[t][1] <= caps[k][1] && types[t][2] <= caps[k][2] && ((caps[k][3] >> types[t][3]) & 1)) {
+        if (types[t][0] <= caps[k][0] && types[t][1] <= caps[k][1] && types[t][2] <= caps[k][2] && ((caps[k][3] >> types[t][3]) & 1) &&
+            (types[t][4] == 0 || caps[k][4] >= 1)) {
+          // caps[k][4]: 0 no state that offers into another member, 1 any state, 2 a row reserved for such states
           admits[t] |= 1u << k;
-          if (types[t][1] == caps[k][1]) own[t] |= 1u << k;     // S rows are kept for the states that need them
+          // S rows and the reserved rows are kept for the states that need them
+          const bool reserved = caps[k][4] == 2;
+          if (reserved ? types[t][4] == 1 : types[t][1] == caps[k][1]) own[t] |= 1u << k;
         }
     rows->assign(N, -1);
     for (int g = 0; g < G; ++g) {
@@ -255,7 +274,7 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G) {
     return true;
   };
   auto score = [&](const std::vector<int>& rows, int* readsOut, int* backOut, int* entriesOut) -> double {
-    std::vector<Type> shape(K, Type{0, 0, 0, 0});
+    std::vector<Type> shape(K, Type{0, 0, 0, 0, 0});
     for (int j = 0; j < N; ++j)
       for (int q = 0; q < 3; ++q) shape[rows[j]][q] = std::max(shape[rows[j]][q], type[j][q]);
     std::vector<char> inUse(K, 0);
@@ -321,10 +340,15 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G) {
     for (int g = 0; g < G; ++g) biggest = std::max(biggest, (long)walkOf[g].size());
     // K is even (lattice pairs); when the states fit K-1 rows the last one may stay empty and
     // costs nothing in a sweep -- tried both ways
+    // (when the rows reserved for the states that offer into other members leave no program -- tiny machines cut into
+    //  clusters -- every row may hold them instead)
+    for (int attempt = 0; attempt < 2 && bestScore < 0; ++attempt, nRemoteRows = nRemoteSRows = 0)
     for (int KU = K; KU >= std::max(1, K - 1); --KU)
     for (int nS = minS; nS <= std::min(KU, minS + 2); ++nS) {
-      if (ldsNeed(nS) > kTierALdsLimit) { why = "LDS working set " + std::to_string(ldsNeed(nS)) + " B exceeds one CU"; continue; }
+      if (ldsNeed(nS + nRemoteSRows) > kTierALdsLimit) { why = "LDS working set " + std::to_string(ldsNeed(nS + nRemoteSRows)) + " B exceeds one CU"; continue; }
       if ((long)KU * T < biggest) continue;
+      if (nS + nRemoteRows > KU) continue;
+      const int KUL = KU - nRemoteRows;                 // rows in front of them
       for (int groups = 1; groups <= std::max(1, std::min(3, nS)); ++groups) {
         for (int ascending = 0; ascending < 2; ++ascending)
         for (int plainRows = 0; plainRows < 2; ++plainRows)
@@ -333,14 +357,15 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G) {
           std::vector<int> isS(K, 0);
           for (int g = 0, left = nS; g < groups && nS > 0; ++g) {
             const int len = left / (groups - g);
-            const int at = g * KU / groups;
-            for (int i = 0; i < len; ++i) isS[std::min(KU - 1, at + i)] = 1;
+            const int at = g * KUL / groups;
+            for (int i = 0; i < len; ++i) isS[std::min(KUL - 1, at + i)] = 1;
             left -= len;
           }
           if (std::accumulate(isS.begin(), isS.end(), 0) != nS) continue;   // runs collided
           std::vector<Type> caps(K);
           int seenS = 0, seenP = 0, nPlainRows = 0;
           for (int k = 0; k < K; ++k) {
+            if (k >= KUL && k < KU) { caps[k] = Type{maxOut, k - KUL < nRemoteSRows ? 1 : 0, 1, 0xff, 2}; continue; }
             const std::vector<int>& sorted = isS[k] ? outS : outP;
             int& seen = isS[k] ? seenS : seenP;
             int cap = maxOut;
@@ -355,7 +380,7 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G) {
               const size_t have = (size_t)(std::upper_bound(outPlainP.begin(), outPlainP.end(), cap) - outPlainP.begin());
               if (have >= (size_t)(nPlainRows + 1) * T) { generic = 0; ++nPlainRows; }
             }
-            caps[k] = k < KU ? Type{cap, isS[k], generic, 0xff} : Type{-1, -1, -1, 0};   // closed rows admit nothing
+            caps[k] = k < KU ? Type{cap, isS[k], generic, 0xff, nRemoteRows == 0 ? 1 : 0} : Type{-1, -1, -1, 0, -1};   // closed rows admit nothing
             ++seen;
           }
           if (typedS && nS > 0) {
@@ -441,7 +466,7 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G) {
             for (int k2 = 0; k2 < K; ++k2) {
               if (k2 == k || fill[(size_t)part[j] * K + k2] >= T) continue;
               const Type& c2 = bestCaps[k2];
-              if (type[j][0] > c2[0] || type[j][1] > c2[1] || type[j][2] > c2[2] || !((c2[3] >> type[j][3]) & 1)) continue;
+              if (type[j][0] > c2[0] || type[j][1] > c2[1] || type[j][2] > c2[2] || !((c2[3] >> type[j][3]) & 1) || (type[j][4] && c2[4] == 0) || (!type[j][4] && c2[4] == 2)) continue;
               if (type[j][0] > nOutNow[k2]) continue;      // would grow the row's entry registers
               const int have = common(k2);
               const int mine = attr == 0 ? clsOf(j) : kindOf(j);

@@ -578,8 +578,10 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
                 if (ln == 0) __hip_atomic_store(&SY[2 + member], ge + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 declared = true;
               } else if (__all(ln < 2 || ln >= 2 + G_ || w == ge + 1u)) {
-                // every member idle at ge: the verdict stands if GE has not moved since those words were read
-                if (wLoad(&SY[0]) == ge) {
+                // every member idle at ge: the verdict stands if GE has not moved since those words were read.  GE and
+                // up to 14 idle words share one 64-byte line, which one wave-wide load reads as a unit: the snapshot
+                // itself shows GE == ge; larger clusters read GE once more.
+                if (G_ <= 14 || wLoad(&SY[0]) == ge) {
                   if (ln == 0) {
                     *geL = ge;
                     __hip_atomic_store(doneL, colSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
