@@ -12,7 +12,7 @@
 namespace dnas {
 namespace {
 
-constexpr int kMaxEntries = 40;   // entry registers per thread the kernel can afford
+constexpr int kMaxEntries = 40;   // entry registers per thread the kernel can afford (at 1024 threads: 128 registers each)
 constexpr int kWalk = 30;         // length of the walks the sweep estimate looks at
 
 struct Edge { int src, dst, sc, base, isNull; };
@@ -53,9 +53,12 @@ std::vector<int> partitionStates(int N, const std::vector<Edge>& edges, const st
   return part;
 }
 
-TierAPlan buildPlan(const dnas_flat_model& fm, const int G) {
+TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T) {
   TierAPlan p;
-  const int N = fm.n_states, D = fm.max_dup_len, T = kTierAThreads;
+  const int N = fm.n_states, D = fm.max_dup_len;
+  if (T != 1024 && T != 512) { TierAPlan bad; bad.whyNot = "work-groups of 512 or 1024 threads"; return bad; }
+  // a work-group fills a CU either way: 16 waves of 128 registers, or 8 waves of 256 with twice the rows per thread
+  const int maxRows = kTierAMaxRows * 1024 / T, maxEntries = kMaxEntries * 1024 / T;
   p.N = N; p.D = D; p.T = T; p.G = G;
   auto no = [&](const std::string& why) { p.ok = false; p.whyNot = why; return p; };
   if (D > 8) return no("more than 8 duplication lanes");
@@ -71,7 +74,7 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G) {
     K = 2 * (int)((perMember * 100 / 86 + 2 * T - 1) / (2 * T));
     K = std::max(K, 2);
   }
-  if (K > kTierAMaxRows) return no("more than " + std::to_string((long)kTierAMaxRows * T * G * (G == 1 ? 100 : 86) / 100) + " states");
+  if (K > maxRows) return no("more than " + std::to_string((long)maxRows * T * G * (G == 1 ? 100 : 86) / 100) + " states");
   p.K = K; p.NSm = K * T; p.NS = G * K * T;
 
   // score classes: 0.0 plus up to three distinct input-symbol log-probabilities
@@ -151,7 +154,7 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G) {
   p.nGRows = nInboxRows;
   p.nGSRows = nInboxSRows;
   if ((long)G * nInboxRows * T > (1l << 20)) return no("more than 2^20 exchange cells");
-  if (nInboxRows > 6) return no("more than " + std::to_string(6 * T) + " states of a member are fed by other members");
+  if (nInboxRows > 7) return no("more than " + std::to_string(7 * T) + " states of a member are fed by other members");
 
   std::vector<Type> type(N);
   int maxOut = 0;
@@ -417,7 +420,7 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G) {
             if (sscanf(pick, "%d,%d,%d,%d,%d,%d", &a0, &a1, &a2, &a3, &a4, &a5) == 6 &&
                 (a0 != KU || a1 != nS || a2 != groups || a3 != ascending || a4 != plainRows || a5 != typedS)) continue;
           }
-          if (entries > kMaxEntries) { why = "row shapes need " + std::to_string(entries) + " entry registers per thread"; continue; }
+          if (entries > maxEntries) { why = "row shapes need " + std::to_string(entries) + " entry registers per thread"; continue; }
           if (bestScore < 0 || sc < bestScore) {
             bestScore = sc; rowOfState = rows; bestCaps = caps;
             p.sweepReads = reads; p.backEdgesOnWalk = back;
@@ -582,7 +585,7 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G) {
   int nEnt = 0;
   std::vector<int> rowOff(K, 0);
   for (int k = 0; k < K; ++k) { rowOff[k] = nEnt; nEnt += std::max(p.rows[k].nOut, 0); }
-  if (nEnt > kMaxEntries) return no("row shapes need " + std::to_string(nEnt) + " entry registers per thread");
+  if (nEnt > maxEntries) return no("row shapes need " + std::to_string(nEnt) + " entry registers per thread");
   p.nEntries = std::max(nEnt, 1);
   p.fillRatio = nEnt ? (double)real / ((double)nEnt * T * G) : 1.0;
 
@@ -672,22 +675,34 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G) {
 
 }  // namespace
 
-TierAPlan buildTierAPlan(const dnas_flat_model& fm) { return buildPlan(fm, 1); }
+TierAPlan buildTierAPlan(const dnas_flat_model& fm, int threads) { return buildPlan(fm, 1, threads); }
 
-TierAPlan buildClusterPlan(const dnas_flat_model& fm, int G) {
+TierAPlan buildClusterPlan(const dnas_flat_model& fm, int G, int threads) {
   if (G < 2) { TierAPlan p; p.whyNot = "a cluster has at least two members"; return p; }
-  return buildPlan(fm, G);
+  return buildPlan(fm, G, threads);
 }
 
-TierAPlan buildSmallestClusterPlan(const dnas_flat_model& fm, int gMin) {
+TierAPlan buildSmallestClusterPlan(const dnas_flat_model& fm, int gMin, int threads) {
   TierAPlan last;
   const int lo = std::max(2, std::max(gMin, (int)(((long)fm.n_states * 100 / 93 + (long)kTierAMaxRows * kTierAThreads - 1) / ((long)kTierAMaxRows * kTierAThreads))));
   for (int G = lo; G <= kTierCMaxMembers; ++G) {
-    last = buildPlan(fm, G);
+    last = buildPlan(fm, G, threads);
     if (last.ok) return last;
   }
   if (last.whyNot.empty()) last.whyNot = "more than " + std::to_string(kTierCMaxMembers) + " work-groups per read";
   return last;
+}
+
+// Tier C as the runtime asks for it: members = 0 -> the smallest cluster; threads = 0 -> work-groups of 512 threads
+// (8 waves of 256 registers, twice the rows per thread: no register spills, and the machine fits fewer CUs) when that
+// needs no more work-groups per read than 1024-thread ones (measured faster at equal size), else 1024.
+TierAPlan chooseClusterPlan(const dnas_flat_model& fm, int members, int threads) {
+  auto build = [&](int t) { return members >= 2 ? buildClusterPlan(fm, members, t) : buildSmallestClusterPlan(fm, 2, t); };
+  if (threads == 512 || threads == 1024) return build(threads);
+  TierAPlan wide = build(1024), narrow = build(512);
+  if (!narrow.ok) return wide;
+  if (!wide.ok) return narrow;
+  return narrow.G <= wide.G ? narrow : wide;
 }
 
 }  // namespace dnas

@@ -68,10 +68,13 @@ constexpr int kTierCMaxMembers = 32;                  // one XCD
 constexpr size_t kTierALdsLimit = 160 * 1024 - 1024;  // leave room for the static reduction buffer
 
 // One work-group per read; fails (ok = false) when the machine does not fit one CU.
-TierAPlan buildTierAPlan(const dnas_flat_model& fm);
+// threads: 1024 (16 waves of 128 registers) or 512 (8 waves of 256 registers, twice the rows per thread).
+TierAPlan buildTierAPlan(const dnas_flat_model& fm, int threads = kTierAThreads);
 // G work-groups per read (G >= 2); fails when the states do not fit G CUs or no common row program exists.
-TierAPlan buildClusterPlan(const dnas_flat_model& fm, int G);
+TierAPlan buildClusterPlan(const dnas_flat_model& fm, int G, int threads = kTierAThreads);
 // The smallest cluster that fits (tries G = gMin .. kTierCMaxMembers).
-TierAPlan buildSmallestClusterPlan(const dnas_flat_model& fm, int gMin = 2);
+TierAPlan buildSmallestClusterPlan(const dnas_flat_model& fm, int gMin = 2, int threads = kTierAThreads);
+// What the runtime uses for tier C: members = 0 -> smallest cluster, threads = 0 -> 512 when that needs fewer members.
+TierAPlan chooseClusterPlan(const dnas_flat_model& fm, int members, int threads);
 
 }  // namespace dnas

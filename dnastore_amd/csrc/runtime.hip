@@ -187,8 +187,8 @@ extern "C" int dnas_model_create(const dnas_flat_model* fm, int device_id, size_
   return dnas_model_create_ex(fm, device_id, arena_bytes, nullptr, out);
 }
 
-// options: "key=value,key=value"; keys tier (A|B|C), cluster (work-groups per read), max_clusters, max_slots,
-// cluster_timeout_s.  A key that is absent falls back to the environment variable DNAS_<KEY>.
+// options: "key=value,key=value"; keys tier (A|B|C), cluster (work-groups per read), threads (512 | 1024 per work-group),
+// max_clusters, max_slots, cluster_timeout_s.  A key that is absent falls back to the environment variable DNAS_<KEY>.
 extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, size_t arena_bytes, const char* options,
                                     dnas_model** out) {
   if (!fm || !out) return dnas::fail(DNAS_E_INVALID, "dnas_model_create: null argument");
@@ -259,21 +259,22 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
     const char* forceOpt = opt("tier");
     const std::string force = forceOpt ? forceOpt : "";
     const char want = !force.empty() ? (char)(force[0] & ~0x20) : 0;
-    int wantG = 0;
+    int wantG = 0, wantT = 0;
     if (const char* s = opt("cluster")) wantG = atoi(s);
+    if (const char* s = opt("threads")) wantT = atoi(s);
     if (want == 'B') {
       m->tierNote = "tier B forced by DNAS_TIER";
     } else {
       std::string whyNotA;
       if (want != 'C' && wantG < 2) {
-        m->plan = dnas::buildTierAPlan(*fm);
+        m->plan = dnas::buildTierAPlan(*fm, wantT ? wantT : dnas::kTierAThreads);
         if (!m->plan.ok) whyNotA = m->plan.whyNot;
       } else {
         m->plan.ok = false;
         whyNotA = "cluster forced";
       }
       if (!m->plan.ok && want != 'A') {
-        m->plan = wantG >= 2 ? dnas::buildClusterPlan(*fm, wantG) : dnas::buildSmallestClusterPlan(*fm);
+        m->plan = dnas::chooseClusterPlan(*fm, wantG, wantT);
         if (!m->plan.ok) m->plan.whyNot = "one work-group: " + whyNotA + "; cluster: " + m->plan.whyNot;
       }
       if (!m->plan.ok) {
@@ -763,7 +764,7 @@ extern "C" int dnas_model_read_events(dnas_model* m, int64_t read_index, uint64_
 extern "C" int dnas_tierc_precompile(const dnas_flat_model* fm, int32_t members, char* note, size_t note_cap) {
   if (!fm) return dnas::fail(DNAS_E_INVALID, "null argument");
   try {
-    const dnas::TierAPlan p = members >= 2 ? dnas::buildClusterPlan(*fm, members) : dnas::buildSmallestClusterPlan(*fm);
+    const dnas::TierAPlan p = dnas::chooseClusterPlan(*fm, members, 0);
     if (!p.ok) return dnas::fail(DNAS_E_UNSUPPORTED, p.whyNot);
     (void)dnas::jitCompile(p.defines, p.key);
     const std::string msg = "tier C: G=" + std::to_string(p.G) + " K=" + std::to_string(p.K) + " inbox rows " + std::to_string(p.nGRows) +
@@ -785,8 +786,7 @@ extern "C" int dnas_tierc_plan(const dnas_flat_model* fm, int32_t members, int32
                                uint32_t* fold) {
   if (!fm || !info) return dnas::fail(DNAS_E_INVALID, "null argument");
   try {
-    const dnas::TierAPlan p = members >= 2 ? dnas::buildClusterPlan(*fm, members)
-                                           : (members == 1 ? dnas::buildTierAPlan(*fm) : dnas::buildSmallestClusterPlan(*fm));
+    const dnas::TierAPlan p = members == 1 ? dnas::buildTierAPlan(*fm) : dnas::chooseClusterPlan(*fm, members, 0);
     if (!p.ok) return dnas::fail(DNAS_E_UNSUPPORTED, p.whyNot);
     info[0] = p.G; info[1] = p.K; info[2] = p.T; info[3] = p.nEntries; info[4] = p.nSRows; info[5] = p.nGRows; info[6] = info[7] = 0;
     if (row_shapes)

@@ -125,7 +125,8 @@ void dnas_flat_free(dnas_flat *f);
  * arena_bytes = 0 picks a default (a fraction of free HBM). */
 int dnas_model_create(const dnas_flat_model *fm, int device_id, size_t arena_bytes, dnas_model **out);
 /* The same with options, "key=value,key=value" (NULL: none).  Keys: tier = A | B | C (force a fill kernel; failing
- * to provide it is then an error), cluster = work-groups per read for tier C, max_clusters, max_slots (reads per
+ * to provide it is then an error), cluster = work-groups per read for tier C, threads = 512 | 1024 per work-group
+ * (default 1024 for tier A; tier C takes 512 when the machine then fits fewer work-groups), max_clusters, max_slots (reads per
  * fill launch), cluster_timeout_s (tier C watchdog per lattice column).  A key that is absent falls back to the
  * environment variable DNAS_<KEY IN UPPER CASE>. */
 int dnas_model_create_ex(const dnas_flat_model *fm, int device_id, size_t arena_bytes, const char *options,
