@@ -54,7 +54,7 @@ def _compose(da, *parts):
 def workload(da, config, variant):
     """-> dict(machine, payload_bytes, default_reads, name)."""
     if config == 1:
-        return dict(machine=_compose(da, "flusher.json", "mixradar6.json", "l4c4.json"), payload_bytes=128, default_reads=96,
+        return dict(machine=_compose(da, "flusher.json", "mixradar6.json", "l4c4.json"), payload_bytes=128, default_reads=64,
                     name="configs[1]: ~980-nt reads through flusher*mixradar6*l4c4 (46670 states)")
     if config == 2:
         return dict(machine=da.Machine.fromFile(MACHINE), payload_bytes=29, default_reads=10000,
