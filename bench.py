@@ -302,11 +302,16 @@ def main():
             extra["value_pcie_inclusive"] = shard_nt / (time.perf_counter() - tp)
             # ---- BASELINE configs[1] names ONE read: its latency
             if args.config == 1:
-                dec.decode(my_reads[:1])
+                # the default plan is the throughput one (512-thread work-groups: the machine on 4 CUs per read); for one
+                # read alone 1024-thread work-groups (5 CUs per read, shorter sweeps) are the faster choice: "threads=1024"
+                dec_lat = da.ViterbiDecoder(machine, params, device=local_rank, options="threads=1024")
+                dec_lat.decode(my_reads[:1])
                 tp = time.perf_counter()
-                dec.decode(my_reads[:1])
+                dec_lat.decode(my_reads[:1])
                 extra["latency_ms_single_read"] = (time.perf_counter() - tp) * 1e3
-                extra["fill_ms_single_read"] = dec.stats()["fill_ms"]
+                extra["fill_ms_single_read"] = dec_lat.stats()["fill_ms"]
+                extra["single_read_plan"] = dec_lat.tier[:40]
+                dec_lat.close()
             # ---- parity spot check + CPU baseline (rank 0, N = 1 only), outside the timed region
             if args.cpu_seconds > 0:
                 max_nt = 256 if machine.nStates() > 100000 else None
