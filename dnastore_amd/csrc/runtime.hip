@@ -65,6 +65,7 @@ struct dnas_model {
   int device = 0;
   int tier = 0;                 // 1 = tier A (register/LDS-resident JIT kernel, one work-group per read), 2 = tier C (the same
                                 // kernel, a cluster of work-groups per read), 0 = tier B (global-memory kernel)
+  int persistentGroups = 0;     // tier A: work-groups per fill launch that pull reads from a queue (0: one work-group per read)
   int maxClusters = 1;          // tier C: clusters that fit the GPU at once
   double* dXbuf = nullptr;      // tier C: exchange buffers, one per cluster
   unsigned* dSync = nullptr;    // tier C: sync blocks (64 u32 per cluster)
@@ -353,6 +354,9 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
     // (the XCD's 4 MB L2 holds the S history of ~17 work-groups).  Measured on MI355X with the bench
     // workload: three rounds of 30 work-groups per XCD (720 reads) per launch, 48.8 ms, is the best
     // point; 2 x 255 = 510 reads cost 48 ms (a third round on the traceback's XCD), 500 reads 37 ms.
+    // Round 2 re-measured this with persistent work-groups that pull reads from a queue (option persistent=W, kept
+    // for experiments): a round takes 16.0-16.4 ms for any W from 208 to 240 work-groups and 18 ms at 248 (the XCDs'
+    // L2s), with or without the queue -- 3 x 240 stays the best point, and the queue buys nothing at whole rounds.
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 1) {
       const int xcds = std::max(1, cus / 32);
@@ -361,6 +365,11 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
   }
   if (m->tier == 2) m->maxSlots = 1 << 20;   // persistent clusters walk any number of reads: a launch is bounded by the arena only
   if (const char* s = opt("max_slots")) m->maxSlots = std::max(1, atoi(s));
+  if (const char* s = opt("persistent")) m->persistentGroups = std::max(0, atoi(s));
+  if (const char* s = opt("arena_fraction")) {
+    const double f = atof(s);
+    if (f > 0.05 && f < 0.95 && !arena_bytes) m->arenaCap = (size_t)((double)freeB * f);
+  }
   *out = m;
   return DNAS_OK;
 }
@@ -455,9 +464,11 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
   std::vector<int64_t> batchStart{0};
   size_t used = 0, peak = 0;
   int64_t columns = 0;
-  // equal batches rather than full ones and a remainder
+  // one work-group per read: equal batches rather than full ones and a remainder (a launch costs whole rounds of
+  // work-groups).  Persistent work-groups that pull reads from a queue: full batches (a multiple of the work-groups)
+  // and a remainder, which then only costs the rounds it needs.
   const int64_t nFull = (n_reads + m->maxSlots - 1) / m->maxSlots;
-  const int64_t perBatch = (n_reads + nFull - 1) / nFull;
+  const int64_t perBatch = (m->tier == 1 && m->persistentGroups > 0) ? m->maxSlots : (n_reads + nFull - 1) / nFull;
   for (int64_t i = 0; i < n_reads; ++i) {
     const uint64_t L = read_offsets[order[i] + 1] - read_offsets[order[i]];
     if (L > 0x7ffffff0ull) return dnas::fail(DNAS_E_UNSUPPORTED, "read too long");
@@ -553,6 +564,10 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
       TierALaunch la{m->argsA, m->dEntTab, m->dMetaTab, d_bases, m->dReadOff, m->dBatchRead + s, m->dSlotOff + s,
                      m->arena, d_out_loglike, m->dRounds, nullptr, nullptr, nullptr, 0, nB, 0ull};
       unsigned grid = (unsigned)nB;
+      if (m->tier == 1 && m->persistentGroups > 0 && nB > m->persistentGroups) {
+        grid = (unsigned)m->persistentGroups;      // the work-groups pull the reads beyond the first `grid` from a queue
+        HIP_TRY(hipMemsetAsync(m->dRounds + 9, 0, sizeof(unsigned long long), m->stream));
+      }
       if (m->tier == 2) {
         // a cluster of G work-groups per read, persistent over the reads of the launch.  Blocks b and b + 8 share
         // an XCD (observed dispatch order; the kernel is correct under any placement): the members of a cluster are

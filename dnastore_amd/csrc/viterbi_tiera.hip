@@ -324,7 +324,10 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
     }
   };
 
-  for (int r = rFirst; r < rEnd && !aborted; r += rStep) {
+  // Tier A with fewer work-groups than reads (a persistent launch): a work-group that has finished a read takes the
+  // next one from the launch's queue word, roundsTotal[9] (zeroed by the launcher); reads are sorted longest first.
+  if constexpr (G_ == 1) { if (nReads > (int)gridDim.x) rEnd = nReads; }
+  for (int r = rFirst; r < rEnd && !aborted; ) {
   const int read = batchRead[r];
   const unsigned char* seq = bases + readOff[read];
   const int L = (int)(readOff[read + 1] - readOff[read]);
@@ -760,6 +763,15 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
     if constexpr (G_ > 1) { if (owner) outLoglike[read] = red[0]; }
   }
   __syncthreads();             // red[] is free again
-  }   // reads of this cluster
+  if constexpr (G_ > 1) {
+    r += rStep;
+  } else {
+    if (rEnd == rFirst + 1) break;
+    if (tid == 0) *geL = (unsigned)gridDim.x + (unsigned)atomicAdd(roundsTotal + 9, 1ull);
+    __syncthreads();
+    r = (int)*geL;
+    __syncthreads();
+  }
+  }   // reads of this work-group / cluster
   if (tid == 0) atomicAdd(roundsTotal, (unsigned long long)rounds);
 }
