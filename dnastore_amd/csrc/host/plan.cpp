@@ -59,6 +59,8 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T) {
   if (T != 1024 && T != 512) { TierAPlan bad; bad.whyNot = "work-groups of 512 or 1024 threads"; return bad; }
   // a work-group fills a CU either way: 16 waves of 128 registers, or 8 waves of 256 with twice the rows per thread
   const int maxRows = kTierAMaxRows * 1024 / T, maxEntries = kMaxEntries * 1024 / T;
+  bool pairSweep = T == 512;    // 2 waves per SIMD hide little LDS latency: read two rows' accumulators at a time
+  if (const char* e = getenv("DNAS_PAIR_SWEEP")) pairSweep = atoi(e) != 0;
   p.N = N; p.D = D; p.T = T; p.G = G;
   auto no = [&](const std::string& why) { p.ok = false; p.whyNot = why; return p; };
   if (D > 8) return no("more than 8 duplication lanes");
@@ -245,7 +247,9 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T) {
         if (!avail) avail = admits[typeOf[j]] & freeRows & ~exclude;
         if (!avail) return -1;
         const int par = parent[j];
-        const int start = (par >= 0 && (*rows)[par] >= 0) ? (*rows)[par] + 1 : 0;
+        // (pair sweeps: the kernel reads the accumulators of rows 2m and 2m+1 together, so a chain runs along rows of
+        //  one parity)
+        const int start = (par >= 0 && (*rows)[par] >= 0) ? (*rows)[par] + (pairSweep ? 2 : 1) : 0;
         const unsigned fw = start < 32 ? avail & ~((1u << start) - 1u) : 0u;
         return __builtin_ctz(fw ? fw : avail);
       };
@@ -665,10 +669,10 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T) {
          << p.rows[k].gOut << "}";
   }
   defs << "-DDNAS_T=" << T << "\n-DDNAS_K=" << K << "\n-DDNAS_D=" << D << "\n-DDNAS_NS=" << p.NSm << "\n-DDNAS_SROWS=" << p.nSRows
-       << "\n-DDNAS_NCLS=" << p.nClasses << "\n-DDNAS_G=" << G << "\n-DDNAS_GROWS=" << nInboxRows << "\n-DDNAS_GSROWS=" << nInboxSRows << "\n-DDNAS_ROWS=" << rows.str();
+       << "\n-DDNAS_NCLS=" << p.nClasses << "\n-DDNAS_G=" << G << "\n-DDNAS_GROWS=" << nInboxRows << "\n-DDNAS_GSROWS=" << nInboxSRows << "\n-DDNAS_PAIRSWEEP=" << (pairSweep ? 1 : 0) << "\n-DDNAS_ROWS=" << rows.str();
   p.defines = defs.str();
   p.key = "T" + std::to_string(T) + "K" + std::to_string(K) + "D" + std::to_string(D) + "S" + std::to_string(p.nSRows) + "C" +
-          std::to_string(p.nClasses) + "G" + std::to_string(G) + "X" + std::to_string(nInboxRows) + "x" + std::to_string(nInboxSRows) + "R" + rows.str();
+          std::to_string(p.nClasses) + "G" + std::to_string(G) + "X" + std::to_string(nInboxRows) + "x" + std::to_string(nInboxSRows) + (pairSweep ? "p" : "") + "R" + rows.str();
   p.ok = true;
   return p;
 }

@@ -80,6 +80,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 #ifndef DNAS_GSROWS
 #define DNAS_GSROWS DNAS_GROWS
 #endif
+#ifndef DNAS_PAIRSWEEP
+#define DNAS_PAIRSWEEP 0
+#endif
 
 // kernel-argument block (mirrors runtime.hip TierAArgs)
 struct TierAArgs {
@@ -464,16 +467,16 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
             }
           });
         }
-        static_for<0, K>([&](auto kc) {
+        // One row of the sweep; dIn / scIn: its accumulators as read.
+        auto rowEval = [&](auto kc, double dIn, double scIn) {
           constexpr int k = kc.value, o = rowOffset(k);
           if constexpr (!rowLive(k)) return;
 
           // D is exactly what the in-edges have offered; a row with no S cells can only move when D
           // moved.  The first sweep of a column finds Dv == kFresh (no D cell is ever +inf) and offers
           // the starting values.
-          double d, s = S[k];
-          d = ldsRead(ldsB, DC_OWN(k));
-          if constexpr (kRows[k].sIdx >= 0) s = dmax(s, ldsRead(ldsB, SC_OWN(k)));
+          double d = dIn, s = S[k];
+          if constexpr (kRows[k].sIdx >= 0) s = dmax(s, scIn);
           bool grew = d != Dv[k];
           if constexpr (kRows[k].sIdx >= 0) grew = grew || s != S[k];
           if (grew) {
@@ -513,7 +516,28 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
               }
             });
           }
+        };
+#if DNAS_PAIRSWEEP
+        // rows two at a time: the accumulators of both are on their way before the first is evaluated (the plan lays a
+        // chain along rows of one parity, so the second row's cells rarely depend on what the first one offers)
+        static_for<0, K / 2>([&](auto mc) {
+          constexpr int k0 = 2 * mc.value, k1 = k0 + 1;
+          double dA = kNegInf, sA = kNegInf, dB = kNegInf, sB = kNegInf;
+          if constexpr (rowLive(k0)) { dA = ldsRead(ldsB, DC_OWN(k0)); if constexpr (kRows[k0].sIdx >= 0) sA = ldsRead(ldsB, SC_OWN(k0)); }
+          if constexpr (rowLive(k1)) { dB = ldsRead(ldsB, DC_OWN(k1)); if constexpr (kRows[k1].sIdx >= 0) sB = ldsRead(ldsB, SC_OWN(k1)); }
+          rowEval(IntC<k0>{}, dA, sA);
+          rowEval(IntC<k1>{}, dB, sB);
         });
+#else
+        static_for<0, K>([&](auto kc) {
+          constexpr int k = kc.value;
+          if constexpr (!rowLive(k)) return;
+          double sc = kNegInf;
+          const double d = ldsRead(ldsB, DC_OWN(k));
+          if constexpr (kRows[k].sIdx >= 0) sc = ldsRead(ldsB, SC_OWN(k));
+          rowEval(kc, d, sc);
+        });
+#endif
         ++rounds;
         if constexpr (G_ > 1) {
           // fold the inbox: a cell that raises its state's LDS accumulator counts like an offer of this wave
