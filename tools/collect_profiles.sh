@@ -12,6 +12,7 @@ for c in config1 config2 config3 config3b config4; do
   done
 done
 for f in $P/bench_config*.json; do tail -1 $f > $O/r2_$(basename $f); done
+[ -f $P/bench_config4_1M.json ] && tail -1 $P/bench_config4_1M.json > $O/r2_bench_config4_1M.json
 cp $P/bulk_parity.txt $O/r2_bulk_parity.txt
 python $R/tools/traffic_from_pmc.py $P/config2 viterbi_fill_tiera $O/r2_traffic_config2.json
 python $R/tools/traffic_from_pmc.py $P/config1 viterbi_fill_tiera $O/r2_traffic_config1.json
