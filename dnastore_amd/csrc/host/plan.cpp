@@ -59,7 +59,9 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T) {
   if (T != 1024 && T != 512) { TierAPlan bad; bad.whyNot = "work-groups of 512 or 1024 threads"; return bad; }
   // a work-group fills a CU either way: 16 waves of 128 registers, or 8 waves of 256 with twice the rows per thread
   const int maxRows = kTierAMaxRows * 1024 / T, maxEntries = kMaxEntries * 1024 / T;
-  bool pairSweep = T == 512;    // 2 waves per SIMD hide little LDS latency: read two rows' accumulators at a time
+  // Pair sweeps (the accumulators of rows 2m and 2m+1 read together): +3 % on the 46 670-state machine, -25 % on the
+  // 258 538-state one -- off unless asked for (DNAS_PAIR_SWEEP=1).
+  bool pairSweep = false;
   if (const char* e = getenv("DNAS_PAIR_SWEEP")) pairSweep = atoi(e) != 0;
   p.N = N; p.D = D; p.T = T; p.G = G;
   auto no = [&](const std::string& why) { p.ok = false; p.whyNot = why; return p; };
@@ -188,7 +190,11 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T) {
     nRemoteRows = std::max(nRemoteRows, withS + (remoteOutOf[g] - remoteOutSOf[g] + T - 1) / T);
   }
   nRemoteRows = std::max(nRemoteRows, nRemoteSRows);
-  if (getenv("DNAS_PLAN_NO_REMOTE_ROWS")) nRemoteRows = nRemoteSRows = 0;
+  // Measured: reserved rows pay with 512-thread work-groups (+10 % on the 258 538-state machine, 21 members) and under
+  // load, but cost a lone read on 1024-thread work-groups 20 % (more entry registers): on for 512 threads only.
+  bool reserveRows = T == 512;
+  if (const char* e = getenv("DNAS_PLAN_REMOTE_ROWS")) reserveRows = atoi(e) != 0;
+  if (!reserveRows) nRemoteRows = nRemoteSRows = 0;
   if (getenv("DNAS_PLAN_DEBUG") && G > 1) {
     for (int g = 0; g < G; ++g)
       fprintf(stderr, "plan member %d: %zu states, %d fed by other members, %d with null in-edges\n", g, walkOf[g].size(), inboxCount[g], nNullDestOf[g]);
