@@ -14,6 +14,7 @@ done
 log "profiles"
 bash tools/profile_round2.sh config1 --config 1 --reads 64 --steps 2
 NO_PMC=1 bash tools/profile_round2.sh config3b --config 3 --variant b --reads 8 --steps 1
+for c in config2 config3 config4; do mkdir -p $P/$c; done
 for c in "config2 --config 2 --reads 4320" "config3 --config 3 --reads 2160" "config4 --config 4 --reads 125000"; do
   set -- $c; name=$1; shift
   for C in FETCH_SIZE WRITE_SIZE; do
