@@ -83,6 +83,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 #ifndef DNAS_PAIRSWEEP
 #define DNAS_PAIRSWEEP 0
 #endif
+#ifndef DNAS_ENT_ONDEMAND
+#define DNAS_ENT_ONDEMAND 0
+#endif
 
 // kernel-argument block (mirrors runtime.hip TierAArgs)
 struct TierAArgs {
@@ -237,8 +240,15 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
 #define FOLD_SC(f) (((f) >> 16) << 3)
 #define FOLD_HAS_SC(f) ((f) != 0u && ((f) >> 16) != 0xffffu)
 
+  // the out-edge entries: in registers for the whole launch, or (DNAS_ENT_ONDEMAND: the 28-row programs of 512-thread
+  // work-groups would spill) fetched from the table where a row offers -- coalesced, L2 resident
+#if DNAS_ENT_ONDEMAND
+#define ENTRY(i) (entTab[(size_t)(i) * T + opaque((unsigned)tid)])
+#else
   unsigned E[kEntries];
   static_for<0, kEntries>([&](auto m) { E[m.value] = entTab[(size_t)m.value * T + tid]; });
+#define ENTRY(i) opaque(E[i])
+#endif
 #define META(k) (metaTab[(size_t)(k) * T + tid])
   // score of an edge by class: class 0 is 0.0 (adding it is the identity on every value that occurs)
   auto withScore = [&](double v, unsigned cls) -> double {
@@ -361,7 +371,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
         constexpr int k = kc.value, o = rowOffset(k);
         if (rowLive(k) && S[k] > kNegInf) {
           static_for<0, rowOut(k)>([&](auto ec) {
-            const unsigned en = opaque(E[o + ec.value]);
+            const unsigned en = ENTRY(o + ec.value);
             if constexpr (kRows[k].kind == 2) return;             // no emit edge in this row
             if constexpr (kRows[k].gOut != 0) {
               if (kRows[k].gOut == 1 ? ENT_VALID(en) : ENT_GLOBAL(en)) {
@@ -486,7 +496,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
             Dv[k] = d;
             const double xv = dmax(d + a.delExtend, s + a.delOpen);    // viterbi.cpp:124
             static_for<0, rowOut(k)>([&](auto ec) {
-              const unsigned en = opaque(E[o + ec.value]);
+              const unsigned en = ENTRY(o + ec.value);
               if (kRows[k].full != 0 || ENT_VALID(en)) {
                 if constexpr (kRows[k].gOut != 0) {
                   if (kRows[k].gOut == 1 || ENT_GLOBAL(en)) {
