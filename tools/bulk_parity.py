@@ -1,6 +1,7 @@
-"""One-off confidence run: N reads of the bench workload decoded on the GPU and, in parallel on the host
-cores, by the CPU oracle; every decoded string and fp64 log-likelihood must be identical.
-  python tools/bulk_parity.py 2000 14"""
+"""One-off confidence run: N reads of a bench workload decoded on the GPU and, in parallel on the host cores, by the
+CPU oracle; every decoded string and fp64 log-likelihood must be identical.
+  python tools/bulk_parity.py 2000 14            (headline workload, configs[2])
+  python tools/bulk_parity.py 64 14 --config 1   (the 46 670-state composite, tier C)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -8,26 +9,31 @@ import multiprocessing as mp
 
 
 def _oracle_chunk(args):
-    reads, = args
+    machine_json, reads = args
     from oracle import oracle as O
-    import bench
-    orc = O.ViterbiOracle(O.Machine.from_file(bench.MACHINE), O.MutatorParams.from_cli(global_=True))
+    orc = O.ViterbiOracle(O.Machine.from_json(machine_json), O.MutatorParams.from_cli(global_=True))
     return [orc.decode(r) for r in reads]
 
 
 if __name__ == "__main__":
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 500
-    workers = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+    n = int(argv[0]) if len(argv) > 0 else 500
+    workers = int(argv[1]) if len(argv) > 1 else 8
+    config = int(sys.argv[sys.argv.index("--config") + 1]) if "--config" in sys.argv else 2
+    variant = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else "a"
     import bench
     import dnastore_amd as da
-    m = da.Machine.fromFile(bench.MACHINE)
-    reads = bench.make_reads(m, 0, n)
+    wl = bench.workload(da, config, variant)
+    m = wl["machine"]
+    reads = bench.make_reads(m, 0, n, payload_bytes=wl["payload_bytes"])
+    mj = m.toJSON()
     chunks = [reads[i::workers] for i in range(workers)]
     t0 = time.time()
     with mp.get_context("spawn").Pool(workers) as pool:
-        fut = pool.map_async(_oracle_chunk, [(c,) for c in chunks])
+        fut = pool.map_async(_oracle_chunk, [(mj, c) for c in chunks])
         dec = da.ViterbiDecoder(m, da.MutatorParams.fromFlags(global_=True))
         out, ll, st = dec.decode(reads)
+        print("%s; %s" % (wl["name"], dec.tier[:60]))
         print("gpu done in %.1fs: %s" % (time.time() - t0, dec.stats()), flush=True)
         res = fut.get()
     bad = 0
