@@ -20,6 +20,9 @@
 extern "C" __global__ void viterbi_fill_kernel(DevModel, const uint8_t*, const uint64_t*, const int32_t*,
                                                const uint64_t*, double*, double*, unsigned long long*, int);
 extern "C" __global__ void expand_lattice_kernel(DevModel, const uint8_t*, const double*, double*);
+extern "C" __global__ void viterbi_traceback_wave_kernel(DevModel, const uint8_t*, const uint64_t*, const int32_t*,
+                                                         const uint64_t*, const double*, char*, const uint64_t*,
+                                                         uint32_t*, uint8_t*, int, unsigned long long*, const uint64_t*, uint32_t*);
 extern "C" __global__ void fill_neginf_kernel(double*, size_t);
 extern "C" __global__ void check_bases_kernel(const uint8_t*, size_t, unsigned long long*);
 extern "C" __global__ void viterbi_traceback_kernel(DevModel, const uint8_t*, const uint64_t*, const int32_t*,
@@ -65,6 +68,7 @@ struct dnas_model {
   int device = 0;
   int tier = 0;                 // 1 = tier A (register/LDS-resident JIT kernel, one work-group per read), 2 = tier C (the same
                                 // kernel, a cluster of work-groups per read), 0 = tier B (global-memory kernel)
+  bool waveTraceback = true;    // one wave per read for batches of up to 256 reads (option traceback=thread: never)
   int persistentGroups = 0;     // tier A: work-groups per fill launch that pull reads from a queue (0: one work-group per read)
   int maxClusters = 1;          // tier C: clusters that fit the GPU at once
   double* dXbuf = nullptr;      // tier C: exchange buffers, one per cluster
@@ -366,6 +370,7 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
   if (m->tier == 2) m->maxSlots = 1 << 20;   // persistent clusters walk any number of reads: a launch is bounded by the arena only
   if (const char* s = opt("max_slots")) m->maxSlots = std::max(1, atoi(s));
   if (const char* s = opt("persistent")) m->persistentGroups = std::max(0, atoi(s));
+  if (const char* s = opt("traceback")) m->waveTraceback = !(s[0] == 't' || s[0] == 'T');
   if (const char* s = opt("arena_fraction")) {
     const double f = atof(s);
     if (f > 0.05 && f < 0.95 && !arena_bytes) m->arenaCap = (size_t)((double)freeB * f);
@@ -602,6 +607,15 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
     RoctxRange tbRange("viterbi traceback");
     HIP_TRY(hipStreamWaitEvent(m->stream2, m->sync[2 * b], 0));
     HIP_TRY(hipEventRecord(m->events[4 * b + 2], m->stream2));
+    // one wave per read finishes a read 4-5x sooner but costs about three times the CU time: for batches small enough
+    // that the traceback is what the caller waits for (tier C, short jobs); large batches trace back thread-per-read on
+    // two CUs, hidden behind the next batch's fill
+    if (m->waveTraceback && nB <= 256)
+      hipLaunchKernelGGL(viterbi_traceback_wave_kernel, dim3((nB + 3) / 4), dim3(256), 0, m->stream2, d, d_bases,
+                         (const uint64_t*)m->dReadOff, (const int32_t*)(m->dBatchRead + s), (const uint64_t*)(m->dSlotOff + s),
+                         (const double*)m->arena, d_out_sym, (const uint64_t*)m->dOutOff, d_out_len, d_out_status, nB, m->dEvents,
+                         (const uint64_t*)m->dEvOff, m->dEvLen);
+    else
     hipLaunchKernelGGL(viterbi_traceback_kernel, dim3((nB + kTraceThreads - 1) / kTraceThreads), dim3(kTraceThreads), 0,
                        m->stream2, d, d_bases, (const uint64_t*)m->dReadOff, (const int32_t*)(m->dBatchRead + s),
                        (const uint64_t*)(m->dSlotOff + s), (const double*)m->arena, d_out_sym,

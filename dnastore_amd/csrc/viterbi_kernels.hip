@@ -431,3 +431,182 @@ viterbi_traceback_kernel(DevModel m, const uint8_t* __restrict__ bases, const ui
   outLen[read] = (uint32_t)n;
   outStatus[read] = 0;
 }
+
+// The same walk with one WAVE per read: the candidates of a step -- in-edges of the state, its own D and T cells --
+// are dealt over the lanes, each lane fetches its candidate's edge fields and lattice cell, and the wave keeps the
+// first strictly greater one (= the largest value, lowest candidate index among equals: the reference's updateBest
+// order, viterbi.cpp:217-228).  A step then costs three rounds of memory latency (the state's row pointers and
+// context, the edge fields, the cells) instead of one chain per candidate.  grid = ceil(nBatch / 4), block = 256.
+extern "C" __global__ void __launch_bounds__(256)
+viterbi_traceback_wave_kernel(DevModel m, const uint8_t* __restrict__ bases, const uint64_t* __restrict__ readOff,
+                              const int32_t* __restrict__ batchRead, const uint64_t* __restrict__ slotOff,
+                              const double* __restrict__ arena, char* __restrict__ outSym,
+                              const uint64_t* __restrict__ outOff, uint32_t* __restrict__ outLen,
+                              uint8_t* __restrict__ outStatus, int nBatch,
+                              unsigned long long* __restrict__ events, const uint64_t* __restrict__ evOff, uint32_t* __restrict__ evLen) {
+  const int b = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+  const int ln = threadIdx.x & 63;
+  if (b >= nBatch) return;
+  const int read = batchRead[b];
+  const uint8_t* seq = bases + readOff[read];
+  const int L = (int)(readOff[read + 1] - readOff[read]);
+  const double* lat = arena + slotOff[b];
+  const int N = m.N, D_ = m.D;
+  char* out = outSym + outOff[read];
+  const long cap = (long)(outOff[read + 1] - outOff[read]);
+  long n = 0;
+  unsigned long long* ev = events ? events + evOff[read] : nullptr;
+  const long evCap = events ? (long)(evOff[read + 1] - evOff[read]) : 0;
+  long nEv = 0;
+  const int32_t* slotOf = m.slotOf;
+#define WSLOT(st) (slotOf ? slotOf[st] : (st))
+#define WEVENT(type, p, payload) { if (ln == 0 && nEv < evCap) ev[nEv] = ((unsigned long long)(type) << 62) | ((unsigned long long)(unsigned)(p) << 32) | (unsigned long long)(payload); ++nEv; }
+
+  if (!(lattice_cell(m, lat, seq, N - 1, L, 0) > kNegInf)) {  // viterbi.cpp:198-201
+    if (ln == 0) { outLen[read] = 0; outStatus[read] = 1; }   // DNAS_READ_NO_PATH
+    return;
+  }
+  int state = N - 1, pos = L, mut = 0;
+  uint8_t status = 0;
+  double curCell = lattice_cell(m, lat, seq, N - 1, L, 0);
+
+  // running best of a step (uniform over the wave)
+  double best; bool found; int bState, bPos, bMut; double bCell; uint8_t bIn, bEm;
+  // one candidate per lane -> the wave's first strictly greater one, merged into the running best
+  auto offer = [&](bool has, int st, int slot, int ps, int lane_, double tr, uint8_t in, uint8_t em) {
+    double v = kNegInf, sc = kNegInf;
+    if (has) { v = cell_at(m, lat, seq, st, slot, ps, lane_); sc = v + tr; }
+    double bs = sc;
+    int bi = ln;
+    for (int off = 32; off > 0; off >>= 1) {
+      const double os = __shfl_xor(bs, off, 64);
+      const int oi = __shfl_xor(bi, off, 64);
+      if (os > bs || (os == bs && oi < bi)) { bs = os; bi = oi; }
+    }
+    if (bs > best) {            // candidates of earlier calls come first: strictly greater only
+      best = bs; found = true;
+      bState = __shfl(st, bi, 64); bPos = __shfl(ps, bi, 64); bMut = __shfl(lane_, bi, 64); bCell = __shfl(v, bi, 64);
+      bIn = (uint8_t)__shfl((int)in, bi, 64); bEm = (uint8_t)__shfl((int)em, bi, 64);
+    }
+  };
+#define W_INIT() { best = kNegInf; found = false; bIn = 0; bEm = 0; bState = 0; bPos = 0; bMut = 0; bCell = kNegInf; }
+#define W_CHECK() { \
+    const double den_ = fabs(curCell) < 1e-6 ? 1. : curCell; \
+    if (!(fabs((best - curCell) / den_) < 1e-6) || !found) { status = 3; break; } \
+    state = bState; pos = bPos; mut = bMut; curCell = bCell; }
+
+  do {
+    W_INIT();
+    if (m.local) {
+      for (int s0 = 0; s0 < N; s0 += 64) { const int st = s0 + ln; offer(st < N, st < N ? st : 0, st < N ? WSLOT(st) : 0, L, 0, 0., 0, 0); }
+    } else {
+      offer(ln == 0, N - 1, WSLOT(N - 1), L, 0, 0., 0, 0);
+    }
+    W_CHECK();
+
+    while (pos >= 0 && state > 0) {
+      // round 1: what the step needs to know about the state, fetched by different lanes
+      int meta = 0;
+      if (ln == 0) meta = m.einPtr[state]; else if (ln == 1) meta = m.einPtr[state + 1];
+      else if (ln == 2) meta = m.ninPtr[state]; else if (ln == 3) meta = m.ninPtr[state + 1];
+      else if (ln == 4) meta = m.mdl[state]; else if (ln == 5) meta = WSLOT(state);
+      else if (ln >= 8 && ln < 8 + D_) meta = m.ctx[(size_t)state * D_ + (ln - 8)];
+      const int e0 = __shfl(meta, 0, 64), e1 = __shfl(meta, 1, 64), n0 = __shfl(meta, 2, 64), n1 = __shfl(meta, 3, 64);
+      const int mdl = __shfl(meta, 4, 64), ownSlot = __shfl(meta, 5, 64);
+      const int x = pos > 0 ? seq[pos - 1] : 0;
+      const int ctx0 = __shfl(meta, 8, 64);
+      W_INIT();
+      if (mut == 0) {
+        const int nE = pos > 0 ? e1 - e0 : 0, nN = n1 - n0;
+        int extra = 1;                                     // own D
+        const bool hasT = mdl > 0 && pos > 0, hasStart = pos == 0 && m.local;
+        extra += hasT ? 1 : 0;
+        extra += hasStart ? 1 : 0;
+        const int total = nE + nN + extra;
+        for (int c0 = 0; c0 < total; c0 += 64) {
+          const int c = c0 + ln;
+          bool has = c < total;
+          int st = 0, slot = 0, ps = pos, lane_ = 0;
+          double tr = 0.;
+          uint8_t in = 0, em = 0;
+          if (has) {
+            if (c < nE) {
+              const int e = e0 + c;
+              st = m.einSrc[e]; slot = m.einSlot[e]; ps = pos - 1; lane_ = 0;
+              tr = (m.einScore[e] + m.noGap) + m.sub[m.einBase[e] * 4 + x];
+              in = m.einIn[e]; em = (uint8_t)(1 + m.einBase[e]);
+            } else if (c < nE + nN) {
+              const int e = n0 + (c - nE);
+              st = m.ninSrc[e]; slot = m.ninSlot[e]; ps = pos; lane_ = 0; tr = m.ninScore[e]; in = m.ninIn[e];
+            } else {
+              const int q = c - nE - nN;                   // 0: own D, then own T1 (if any), then the local start
+              if (q == 0) { st = state; slot = ownSlot; ps = pos; lane_ = 1; tr = m.delEnd; }
+              else if (q == 1 && hasT) { st = state; slot = ownSlot; ps = pos - 1; lane_ = 2; tr = m.sub[ctx0 * 4 + x]; }
+              else { st = 0; slot = WSLOT(0); ps = 0; lane_ = 0; tr = 0.; }
+            }
+          }
+          offer(has, st, slot, ps, lane_, tr, in, em);
+        }
+        if (ev && bEm && bPos < pos && seq[pos - 1] != (uint8_t)(bEm - 1)) WEVENT(1, pos - 1, ((unsigned)(bEm - 1) << 2) | seq[pos - 1])   // viterbi.cpp:266-267
+      } else if (mut == 1) {
+        const int nE = e1 - e0, nN = n1 - n0, total = 2 * nE + nN;
+        for (int c0 = 0; c0 < total; c0 += 64) {
+          const int c = c0 + ln;
+          const bool has = c < total;
+          int st = 0, slot = 0, lane_ = 0;
+          double tr = 0.;
+          uint8_t in = 0, em = 0;
+          if (has) {
+            if (c < 2 * nE) {
+              const int e = e0 + (c >> 1);
+              st = m.einSrc[e]; slot = m.einSlot[e]; in = m.einIn[e]; em = (uint8_t)(1 + m.einBase[e]);
+              if ((c & 1) == 0) { lane_ = 1; tr = m.einScore[e] + m.delExtend; } else { lane_ = 0; tr = m.einScore[e] + m.delOpen; }
+            } else {
+              const int e = n0 + (c - 2 * nE);
+              st = m.ninSrc[e]; slot = m.ninSlot[e]; lane_ = 1; tr = m.ninScore[e]; in = m.ninIn[e];
+            }
+          }
+          offer(has, st, slot, pos, lane_, tr, in, em);
+        }
+        if (ev && bEm) WEVENT(2, pos, (unsigned)(bEm - 1))                                          // viterbi.cpp:278-279
+      } else {
+        const int k = mut - 2;
+        const bool shift = k < mdl - 1;
+        const int ctxNext = __shfl(meta, 8 + (k + 1 < D_ ? k + 1 : 0), 64);
+        // candidate 0: T(k+1) one column back (if any); then S of this column
+        const int total = shift ? 2 : 1;
+        const bool has = ln < total;
+        const bool first = shift && ln == 0;
+        offer(has, state, ownSlot, first ? pos - 1 : pos, first ? 2 + k + 1 : 0,
+              first ? m.sub[ctxNext * 4 + x] : m.tanDup + m.len[k], 0, 0);
+        if (ev && bMut == 0) {        // viterbi.cpp:288-293: the duplicated bases, outermost first
+          unsigned basesDup = 0;
+          for (int q = k; q >= 0; --q) basesDup = (basesDup << 2) | (unsigned)__shfl(meta, 8 + q, 64);
+          WEVENT(3, pos, ((unsigned)(k + 1) << 16) | basesDup)
+        }
+      }
+      W_CHECK();
+      if (bIn) {  // trace.push_front (viterbi.cpp:299-300): fill the slot from its end
+        if (ln == 0 && n < cap) out[cap - 1 - n] = (char)bIn;
+        ++n;
+      }
+    }
+  } while (false);
+#undef W_INIT
+#undef W_CHECK
+#undef WSLOT
+
+  if (ln == 0 && evLen) evLen[read] = (uint32_t)(nEv < evCap ? nEv : evCap);
+#undef WEVENT
+  if (status == 0 && n > cap) status = 2;  // DNAS_READ_OUT_OVERFLOW
+  if (status != 0) {
+    if (ln == 0) { outLen[read] = 0; outStatus[read] = status; }
+    return;
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (ln == 0) {
+    for (long k2 = 0; k2 < n; ++k2) out[k2] = out[cap - n + k2];  // forward order, moved to the slot's front
+    outLen[read] = (uint32_t)n;
+    outStatus[read] = 0;
+  }
+}
