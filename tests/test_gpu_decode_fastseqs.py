@@ -41,8 +41,11 @@ def test_all_devices_matches_one_device(da, ref_data, tmp_path, monkeypatch):
     assert da.lib.lib().dnas_device_count() >= 1
 
 
-def test_traceback_event_log(da, ref_data):
-    """A substituted, a deleted and a duplicated base in the reference's own reads are found where they are."""
+@pytest.mark.parametrize("kernel", ["wave", "thread"])
+def test_traceback_event_log(da, ref_data, kernel, monkeypatch):
+    """A substituted, a deleted and a duplicated base in the reference's own reads are found where they are -- by the
+    wave-per-read traceback (small batches) and by the thread-per-read one (large batches) alike."""
+    monkeypatch.setenv("DNAS_TRACEBACK", kernel)
     def events(mach, fa, **flags):
         m = da.Machine.fromFile(os.path.join(ref_data, mach))
         recs = da.decode_fastseqs(os.path.join(ref_data, fa), m, da.MutatorParams.fromFlags(**flags), events=True)

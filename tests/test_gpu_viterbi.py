@@ -219,3 +219,27 @@ def test_device_entry_point_rejects_bad_bases_and_stale_lattices(da, ref_data):
         dec.decode_device(off, bad.data_ptr(), sym.data_ptr(), ooff, olen.data_ptr(), llt.data_ptr(), stt.data_ptr())
     assert "DNAS_E_BAD_BASE" in str(e.value)
     dec.close()
+
+
+def test_both_traceback_kernels_agree(da, ref_data):
+    """The wave-per-read traceback (batches of up to 256 reads) and the thread-per-read one (larger batches, or
+    traceback=thread) walk the same lattice to the same strings: noisy reads, local and global."""
+    m = da.Machine.fromFile(os.path.join(ref_data, "s16h74l4c4.json"))
+    rng = random.Random(17)
+    reads = []
+    for i in range(40):
+        dna = list(m.encodeBytes(bytes(rng.randrange(256) for _ in range(2 + i % 6))))
+        for j in range(len(dna)):
+            if rng.random() < 0.03:
+                dna[j] = rng.choice("ACGT")
+        if i % 3 == 0:
+            del dna[rng.randrange(len(dna))]
+        reads.append("".join(dna))
+    for flags in (dict(global_=True), dict()):
+        params = da.MutatorParams.fromFlags(**flags)
+        a = da.ViterbiDecoder(m, params)
+        b = da.ViterbiDecoder(m, params, options="traceback=thread")
+        out_a, ll_a, st_a = a.decode(reads)
+        out_b, ll_b, st_b = b.decode(reads)
+        assert out_a == out_b and np.array_equal(ll_a.view(np.uint64), ll_b.view(np.uint64)) and list(st_a) == list(st_b)
+        a.close(); b.close()
