@@ -609,8 +609,8 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
     HIP_TRY(hipEventRecord(m->events[4 * b + 2], m->stream2));
     // one wave per read finishes a read 4-5x sooner but costs about three times the CU time: for batches small enough
     // that the traceback is what the caller waits for (tier C, short jobs); large batches trace back thread-per-read on
-    // two CUs, hidden behind the next batch's fill
-    if (m->waveTraceback && nB <= 256)
+    // two CUs, hidden behind the next batch's fill -- except the last batch of a call, which has the GPU to itself
+    if (m->waveTraceback && (nB <= 256 || b + 1 == nBatches))
       hipLaunchKernelGGL(viterbi_traceback_wave_kernel, dim3((nB + 3) / 4), dim3(256), 0, m->stream2, d, d_bases,
                          (const uint64_t*)m->dReadOff, (const int32_t*)(m->dBatchRead + s), (const uint64_t*)(m->dSlotOff + s),
                          (const double*)m->arena, d_out_sym, (const uint64_t*)m->dOutOff, d_out_len, d_out_status, nB, m->dEvents,

@@ -40,20 +40,23 @@ def _substitute(rng, dna, rate):
     return "".join(out)
 
 
-@pytest.mark.parametrize("mach,fa,flags,members", [
-    ("l4c4.json", "hello.dup.fa", dict(sub=0., del_open=0., global_=True), 2),
-    ("l4c4.json", "hello.fa", dict(), 3),
-    ("h74l4c4.json", "hello.h74.sub.fa", dict(), 2),
-    ("h74l4c4.json", "hello.h74.sub.fa", dict(global_=True), 4),
-    ("s16mr2l4c4.json", "hello.s16mr2.fa", dict(global_=True), 3),
-    ("s16h74l4c4.json", "hello.s16h74.del.fa", dict(), 2),
-    ("s16h74l4c4.json", "hello.s16h74.del.fa", dict(global_=True), 4),
+@pytest.mark.parametrize("mach,fa,flags,members,threads", [
+    ("l4c4.json", "hello.dup.fa", dict(sub=0., del_open=0., global_=True), 2, 512),
+    ("l4c4.json", "hello.fa", dict(), 3, 1024),
+    ("h74l4c4.json", "hello.h74.sub.fa", dict(), 2, 1024),
+    ("h74l4c4.json", "hello.h74.sub.fa", dict(global_=True), 4, 512),
+    ("s16mr2l4c4.json", "hello.s16mr2.fa", dict(global_=True), 3, 512),
+    ("s16h74l4c4.json", "hello.s16h74.del.fa", dict(), 2, 1024),
+    ("s16h74l4c4.json", "hello.s16h74.del.fa", dict(global_=True), 4, 512),
+    ("s16h74l4c4.json", "hello.s16h74.del.fa", dict(), 3, 512),
 ])
-def test_tier_c_full_lattice_bit_exact(da, oracle_mod, ref_data, mach, fa, flags, members):
+def test_tier_c_full_lattice_bit_exact(da, oracle_mod, ref_data, mach, fa, flags, members, threads):
+    """Both work-group shapes: 512 threads (8 waves, 256 registers each, the tier-C default) and 1024 (tier A's)."""
     O = oracle_mod
     path = os.path.join(ref_data, mach)
-    dec = da.ViterbiDecoder(da.Machine.fromFile(path), da.MutatorParams.fromFlags(**flags), options="tier=C,cluster=%d" % members)
-    assert dec.tier.startswith("tier C: %d work-groups" % members)
+    dec = da.ViterbiDecoder(da.Machine.fromFile(path), da.MutatorParams.fromFlags(**flags),
+                            options="tier=C,cluster=%d,threads=%d" % (members, threads))
+    assert dec.tier.startswith("tier C: %d work-groups" % members) and ("T%dK" % threads) in dec.tier
     orc = O.ViterbiOracle(O.Machine.from_file(path), O.MutatorParams.from_cli(**flags))
     read = da.read_fastseqs(os.path.join(ref_data, fa))[0][1]
     out, ll, st = dec.decode([read])
