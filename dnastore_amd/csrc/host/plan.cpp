@@ -709,7 +709,12 @@ TierAPlan buildSmallestClusterPlan(const dnas_flat_model& fm, int gMin, int thre
 TierAPlan chooseClusterPlan(const dnas_flat_model& fm, int members, int threads) {
   auto build = [&](int t) { return members >= 2 ? buildClusterPlan(fm, members, t) : buildSmallestClusterPlan(fm, 2, t); };
   if (threads == 512 || threads == 1024) return build(threads);
-  TierAPlan wide = build(1024), narrow = build(512);
+  TierAPlan narrow = build(512);
+  // both shapes hold the same number of states per work-group: when the narrow one already gets by with the fewest
+  // work-groups that can hold the machine, the wide one cannot do better (and planning a 258 538-state machine takes seconds)
+  const int fewest = std::max(2, (int)(((long)fm.n_states * 100 / 93 + (long)kTierAMaxRows * kTierAThreads - 1) / ((long)kTierAMaxRows * kTierAThreads)));
+  if (narrow.ok && (members >= 2 || narrow.G <= fewest)) return narrow;
+  TierAPlan wide = build(1024);
   if (!narrow.ok) return wide;
   if (!wide.ok) return narrow;
   return narrow.G <= wide.G ? narrow : wide;
