@@ -24,3 +24,12 @@ struct DevModel {
   double sub[16];
   double len[kMaxLen];
 };
+
+// Bounded-memory decode: a traceback that left the lattice segment it was given, to be picked up over the segment before
+// (viterbi_traceback_wave_kernel).
+struct TracebackWalk {
+  int state, pos, mut;
+  int phase;            // 0: not started, 1: parked, 2: finished
+  double curCell;
+  long long n, nEv;     // symbols / events written so far
+};

@@ -15,14 +15,18 @@
 #include "device_model.h"
 #include "errors.hpp"
 #include "host/plan.hpp"
+#include <cmath>
+
 #include "jit.hpp"
 
+extern "C" __global__ void copy_rows_kernel(double*, const double*, size_t, size_t, size_t);
 extern "C" __global__ void viterbi_fill_kernel(DevModel, const uint8_t*, const uint64_t*, const int32_t*,
-                                               const uint64_t*, double*, double*, unsigned long long*, int);
+                                               const uint64_t*, double*, double*, unsigned long long*, int, const int*);
 extern "C" __global__ void expand_lattice_kernel(DevModel, const uint8_t*, const double*, double*);
 extern "C" __global__ void viterbi_traceback_wave_kernel(DevModel, const uint8_t*, const uint64_t*, const int32_t*,
                                                          const uint64_t*, const double*, char*, const uint64_t*,
-                                                         uint32_t*, uint8_t*, int, unsigned long long*, const uint64_t*, uint32_t*);
+                                                         uint32_t*, uint8_t*, int, unsigned long long*, const uint64_t*, uint32_t*,
+                                                         const int*, TracebackWalk*);
 extern "C" __global__ void fill_neginf_kernel(double*, size_t);
 extern "C" __global__ void check_bases_kernel(const uint8_t*, size_t, unsigned long long*);
 extern "C" __global__ void viterbi_traceback_kernel(DevModel, const uint8_t*, const uint64_t*, const int32_t*,
@@ -62,12 +66,21 @@ struct TierALaunch {
   int nClusters;
   int nReads;
   unsigned long long timeoutTicks;
+  const int* colRange;          // bounded-memory decode: [nReads][2] first and last column of this launch (null: whole reads)
 };
 
 struct dnas_model {
   int device = 0;
   int tier = 0;                 // 1 = tier A (register/LDS-resident JIT kernel, one work-group per read), 2 = tier C (the same
                                 // kernel, a cluster of work-groups per read), 0 = tier B (global-memory kernel)
+  // bounded-memory decode: reads whose lattice does not fit the arena (checkpoint=auto), or every read (always), are
+  // filled in segments of `segmentCols` columns (0: chosen from the arena) from checkpoints, twice -- see DESIGN.md 3.6
+  int checkpointMode = 0;       // 0 auto, 1 always, 2 never
+  int segmentCols = 0;
+  int64_t lastCheckpointed = 0; // reads (in sorted order: the longest) of the last call that went that way
+  int* dColRange = nullptr;
+  uint64_t* dSegSlot = nullptr;
+  TracebackWalk* dWalks = nullptr;
   bool waveTraceback = true;    // one wave per read for batches of up to 256 reads (option traceback=thread: never)
   int persistentGroups = 0;     // tier A: work-groups per fill launch that pull reads from a queue (0: one work-group per read)
   int maxClusters = 1;          // tier C: clusters that fit the GPU at once
@@ -83,6 +96,9 @@ struct dnas_model {
   dnas::TierAPlan plan;
   hipModule_t module = nullptr;
   hipFunction_t fillA = nullptr;
+  hipModule_t moduleSeg = nullptr;  // the same kernel built with -DDNAS_SEGMENTS=1 (bounded-memory decode), compiled at first use
+  hipFunction_t fillSeg = nullptr;
+  std::string jitDefs;
   TierAArgs argsA{};
   unsigned *dEntTab = nullptr, *dMetaTab = nullptr;
   int32_t* dSlotOf = nullptr;
@@ -289,6 +305,7 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
         try {
           std::string defs = m->plan.defines;
           if (const char* extra = getenv("DNAS_TIERA_DEFS")) defs += std::string("\n") + extra;   // diagnostics, e.g. -DDNAS_STAMP
+          m->jitDefs = defs;
           const std::vector<char> code = dnas::jitCompile(defs, m->plan.key);
           if (hipModuleLoadData(&m->module, code.data()) != hipSuccess ||
               hipModuleGetFunction(&m->fillA, m->module, "viterbi_fill_tiera") != hipSuccess)
@@ -371,6 +388,8 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
   if (const char* s = opt("max_slots")) m->maxSlots = std::max(1, atoi(s));
   if (const char* s = opt("persistent")) m->persistentGroups = std::max(0, atoi(s));
   if (const char* s = opt("traceback")) m->waveTraceback = !(s[0] == 't' || s[0] == 'T');
+  if (const char* s = opt("checkpoint")) m->checkpointMode = (s[0] == 'a' && s[1] == 'l') ? 1 : (s[0] == 'n' ? 2 : 0);   // auto | always | never
+  if (const char* s = opt("segment")) m->segmentCols = std::max(0, atoi(s));
   if (const char* s = opt("arena_fraction")) {
     const double f = atof(s);
     if (f > 0.05 && f < 0.95 && !arena_bytes) m->arenaCap = (size_t)((double)freeB * f);
@@ -399,7 +418,11 @@ extern "C" void dnas_model_destroy(dnas_model* m) {
   if (m->dEvents) (void)hipFree(m->dEvents);
   if (m->dEvOff) (void)hipFree(m->dEvOff);
   if (m->dEvLen) (void)hipFree(m->dEvLen);
+  if (m->dColRange) (void)hipFree(m->dColRange);
+  if (m->dSegSlot) (void)hipFree(m->dSegSlot);
+  if (m->dWalks) (void)hipFree(m->dWalks);
   if (m->module) (void)hipModuleUnload(m->module);
+  if (m->moduleSeg) (void)hipModuleUnload(m->moduleSeg);
   if (m->dBatchRead) (void)hipFree(m->dBatchRead);
   if (m->dSlotOff) (void)hipFree(m->dSlotOff);
   if (m->dReadOff) (void)hipFree(m->dReadOff);
@@ -465,40 +488,98 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
   });
   // two arena halves: batch i fills half (i & 1) while the traceback of batch i-1 still reads the other
   const size_t arenaCapDoubles = m->arenaCap / sizeof(double) / 2;
+  auto lenOf = [&](int64_t i) { return (int64_t)(read_offsets[order[(size_t)i] + 1] - read_offsets[order[(size_t)i]]); };
+  for (int64_t i = 0; i < n_reads; ++i)
+    if (lenOf(i) > 0x7ffffff0ll) return dnas::fail(DNAS_E_UNSUPPORTED, "read too long");
+
+  // ---- bounded-memory decode (the reference holds every read's whole lattice, viterbi.h:48-50): the reads whose lattice does
+  // not fit half the arena -- the longest, first in sorted order -- are decoded in groups, in segments of C columns:
+  //   pass 1  fill segment after segment into a work buffer of H + C + 1 columns per read, keeping of every segment only its
+  //           last H columns and the hand-over lane (what the fill of the next segment and a traceback step look back at)
+  //   pass 2  from the last segment to the first: restore the checkpoint in front of the segment, fill it again (the last one
+  //           is still there), and let the traceback walk it; a walk that leaves the segment is parked until the next launch
+  // Fill work doubles; memory per read drops from L + 1 columns to about 2 sqrt((L + 1)(H + 1)).
+  struct CkGroup { int64_t first, n, C, nSeg; size_t workStride, ckStride, tabAt; };
+  std::vector<CkGroup> groups;
+  const size_t H = (size_t)d.D + 1;
+  int64_t nCk = 0;
+  if (m->checkpointMode == 1) nCk = n_reads;
+  else if (m->checkpointMode == 0)
+    while (nCk < n_reads && colDoubles * (size_t)(lenOf(nCk) + 1) + 8 > arenaCapDoubles) ++nCk;
+  size_t ckPeak = 0, ckTab = 0, ckLaunches = 0;
+  {
+    const size_t budget = m->arenaCap / sizeof(double);
+    const int64_t groupMax = m->tier == 2 ? m->maxClusters : m->maxSlots;
+    for (int64_t g0 = 0; g0 < nCk;) {
+      const int64_t Lmax = lenOf(g0);
+      int64_t nG = std::min(nCk - g0, groupMax), C = 0;
+      auto perRead = [&](int64_t c) {
+        return (H + (size_t)c + 1) * colDoubles + 8 + (size_t)(Lmax / c + 1) * (H + 1) * colDoubles;
+      };
+      const int64_t cMin = (int64_t)H + 1;
+      for (;;) {
+        const size_t per = budget / (size_t)nG;
+        if (m->segmentCols > 0) {
+          C = std::max<int64_t>(cMin, m->segmentCols);
+          if (perRead(C) <= per) break;
+        } else {
+          C = std::max<int64_t>(cMin, (int64_t)std::ceil(std::sqrt((double)(Lmax + 1) * (double)(H + 1))));
+          if (perRead(C) <= per) {
+            while (C < Lmax + 1 && perRead(std::min(2 * C, Lmax + 1)) <= per) C = std::min(2 * C, Lmax + 1);
+            break;
+          }
+        }
+        if (nG == 1)
+          return dnas::fail(DNAS_E_NOMEM, "a read of " + std::to_string(Lmax) + " bases needs " + std::to_string(perRead(C) * 8) +
+                                              " bytes of lattice segments and checkpoints; the lattice arena has " + std::to_string(m->arenaCap));
+        nG = (nG + 1) / 2;
+      }
+      CkGroup g{g0, nG, C, Lmax / C + 1, (H + (size_t)C + 1) * colDoubles + 8, (size_t)(Lmax / C + 1) * (H + 1) * colDoubles, ckTab};
+      ckPeak = std::max(ckPeak, (size_t)nG * (g.workStride + g.ckStride));
+      ckTab += (size_t)g.nSeg * (size_t)nG;
+      ckLaunches += 2 * (size_t)g.nSeg;
+      groups.push_back(g);
+      g0 += nG;
+    }
+  }
+  m->lastCheckpointed = nCk;
+
   std::vector<uint64_t> slotOff((size_t)n_reads);
-  std::vector<int64_t> batchStart{0};
+  std::vector<int64_t> batchStart{nCk};
   size_t used = 0, peak = 0;
   int64_t columns = 0;
+  for (int64_t i = 0; i < nCk; ++i) columns += lenOf(i) + 1;
   // one work-group per read: equal batches rather than full ones and a remainder (a launch costs whole rounds of
   // work-groups).  Persistent work-groups that pull reads from a queue: full batches (a multiple of the work-groups)
   // and a remainder, which then only costs the rounds it needs.
-  const int64_t nFull = (n_reads + m->maxSlots - 1) / m->maxSlots;
-  const int64_t perBatch = (m->tier == 1 && m->persistentGroups > 0) ? m->maxSlots : (n_reads + nFull - 1) / nFull;
-  for (int64_t i = 0; i < n_reads; ++i) {
-    const uint64_t L = read_offsets[order[i] + 1] - read_offsets[order[i]];
-    if (L > 0x7ffffff0ull) return dnas::fail(DNAS_E_UNSUPPORTED, "read too long");
+  const int64_t nPlain = n_reads - nCk;
+  const int64_t nFull = std::max<int64_t>(1, (nPlain + m->maxSlots - 1) / m->maxSlots);
+  const int64_t perBatch = (m->tier == 1 && m->persistentGroups > 0) ? m->maxSlots : (nPlain + nFull - 1) / nFull;
+  for (int64_t i = nCk; i < n_reads; ++i) {
+    const uint64_t L = (uint64_t)lenOf(i);
     const size_t need = colDoubles * (size_t)(L + 1) + 8;   // + a spare cell (tier A, local mode: S(N-1, L) before its overwrite)
     if (need > arenaCapDoubles)
       return dnas::fail(DNAS_E_NOMEM, "a single read's lattice (" + std::to_string(need * 8) +
-                                          " bytes) exceeds the lattice arena (" + std::to_string(m->arenaCap) + ")");
+                                          " bytes) exceeds the lattice arena (" + std::to_string(m->arenaCap) + ") and checkpoint=never");
     if (i - batchStart.back() >= perBatch || used + need > arenaCapDoubles) {
       batchStart.push_back(i);
       used = 0;
     }
-    slotOff[i] = used;
+    slotOff[(size_t)i] = used;
     used += need;
     peak = std::max(peak, used);
     columns += (int64_t)L + 1;
   }
-  batchStart.push_back(n_reads);
+  if (nPlain > 0) batchStart.push_back(n_reads);
   m->lastBatchStart = batchStart;
   const bool pingPong = batchStart.size() > 2;          // more than one batch
-  if ((pingPong ? 2 : 1) * peak * sizeof(double) > m->arenaBytes) {
+  const size_t arenaNeed = std::max((pingPong ? 2 : 1) * peak, ckPeak) * sizeof(double);
+  if (arenaNeed > m->arenaBytes) {
     if (m->arena) HIP_TRY(hipFree(m->arena));
     m->arena = nullptr;
     m->arenaBytes = 0;
-    HIP_TRY(hipMalloc((void**)&m->arena, (pingPong ? 2 : 1) * peak * sizeof(double)));
-    m->arenaBytes = (pingPong ? 2 : 1) * peak * sizeof(double);
+    HIP_TRY(hipMalloc((void**)&m->arena, arenaNeed));
+    m->arenaBytes = arenaNeed;
   }
   m->halfDoubles = peak;
   if ((size_t)n_reads + 1 > m->schedCap) {
@@ -534,8 +615,9 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
     HIP_TRY(hipMemcpy(m->dEvOff, m->evOff.data(), ((size_t)n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(m->dEvLen, 0, (size_t)n_reads * sizeof(uint32_t)));
   }
-  const size_t nBatches = batchStart.size() - 1;
-  while (m->events.size() < 4 * nBatches) {
+  const size_t nBatches = batchStart.size() - 1, nGroups = groups.size();
+  const size_t nTimed = nBatches + nGroups;              // 4 timing events each: the groups first, then the batches
+  while (m->events.size() < 4 * nTimed) {
     hipEvent_t e;
     HIP_TRY(hipEventCreate(&e));
     m->events.push_back(e);
@@ -546,8 +628,8 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
     m->sync.push_back(e);
   }
   if (m->tier == 2) {
-    m->syncCheck.assign(nBatches * (size_t)m->maxClusters * 64, 0u);
-    m->syncLaunches = nBatches;
+    m->syncCheck.assign((nBatches + ckLaunches) * (size_t)m->maxClusters * 64, 0u);
+    m->syncLaunches = nBatches + ckLaunches;
   }
   const int maskWords = (d.N + 31) / 32 + 1;
   const size_t ldsBytes = 2 * (size_t)maskWords * sizeof(unsigned);
@@ -558,27 +640,27 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
     m->lastSlotOff = slotOff;
     HIP_TRY(hipMemcpy(m->dSlotOff, slotOff.data(), (size_t)n_reads * sizeof(uint64_t), hipMemcpyHostToDevice));
   }
-  for (size_t b = 0; b < nBatches; ++b) {
-    const int64_t s = batchStart[b];
-    const int nB = (int)(batchStart[b + 1] - s);
-    // the half this batch fills was last read by the traceback of batch b-2
-    if (b >= 2) HIP_TRY(hipStreamWaitEvent(m->stream, m->sync[2 * (b - 2) + 1], 0));
-    HIP_TRY(hipEventRecord(m->events[4 * b], m->stream));
-    { RoctxRange fillRange(m->tier == 2 ? "viterbi fill (tier C)" : (m->tier == 1 ? "viterbi fill (tier A)" : "viterbi fill (tier B)"));
+
+  // one fill launch over nB reads (their indices at batchRead, their lattices at arena + slots[.]), on m->stream
+  size_t syncAt = 0, fillLaunches = 0;
+  auto launchFill = [&](const int32_t* batchRead, const uint64_t* slots, int nB, const int* colRange) -> int {
+    ++fillLaunches;
+    RoctxRange fillRange(m->tier == 2 ? "viterbi fill (tier C)" : (m->tier == 1 ? "viterbi fill (tier A)" : "viterbi fill (tier B)"));
     if (m->tier >= 1) {
-      TierALaunch la{m->argsA, m->dEntTab, m->dMetaTab, d_bases, m->dReadOff, m->dBatchRead + s, m->dSlotOff + s,
-                     m->arena, d_out_loglike, m->dRounds, nullptr, nullptr, nullptr, 0, nB, 0ull};
+      TierALaunch la{m->argsA, m->dEntTab, m->dMetaTab, d_bases, m->dReadOff, batchRead, slots,
+                     m->arena, d_out_loglike, m->dRounds, nullptr, nullptr, nullptr, 0, nB, 0ull, colRange};
       unsigned grid = (unsigned)nB;
-      if (m->tier == 1 && m->persistentGroups > 0 && nB > m->persistentGroups) {
+      if (m->tier == 1 && m->persistentGroups > 0 && nB > m->persistentGroups && !colRange) {
         grid = (unsigned)m->persistentGroups;      // the work-groups pull the reads beyond the first `grid` from a queue
         HIP_TRY(hipMemsetAsync(m->dRounds + 9, 0, sizeof(unsigned long long), m->stream));
       }
+      int nClusters = 0;
       if (m->tier == 2) {
         // a cluster of G work-groups per read, persistent over the reads of the launch.  Blocks b and b + 8 share
         // an XCD (observed dispatch order; the kernel is correct under any placement): the members of a cluster are
         // 8 blocks apart, cluster = (b / 8 / G) * 8 + b % 8.
         const int G = m->plan.G;
-        const int nClusters = std::min(nB, m->maxClusters);
+        nClusters = std::min(nB, m->maxClusters);
         la.xbuf = m->dXbuf; la.syncWords = m->dSync; la.foldTab = m->dFoldTab; la.nClusters = nClusters; la.timeoutTicks = m->timeoutTicks;
         grid = (unsigned)(8 * G * ((nClusters + 7) / 8));
         const size_t nX = m->xStride * (size_t)nClusters;
@@ -588,25 +670,120 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
       }
       size_t laSize = sizeof la;
       void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &la, HIP_LAUNCH_PARAM_BUFFER_SIZE, &laSize, HIP_LAUNCH_PARAM_END};
-      HIP_TRY(hipModuleLaunchKernel(m->fillA, grid, 1, 1, (unsigned)m->plan.T, 1, 1, (unsigned)m->plan.ldsBytes,
+      HIP_TRY(hipModuleLaunchKernel(colRange ? m->fillSeg : m->fillA, grid, 1, 1, (unsigned)m->plan.T, 1, 1, (unsigned)m->plan.ldsBytes,
                                     m->stream, nullptr, config));
       if (m->tier == 2) {
         // the watchdog words of this launch: [1] of every sync block (checked in dnas_model_sync)
-        HIP_TRY(hipMemcpyAsync(m->syncCheck.data() + b * (size_t)m->maxClusters * 64, m->dSync,
-                               (size_t)std::min(nB, m->maxClusters) * 64 * sizeof(unsigned), hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipMemcpyAsync(m->syncCheck.data() + syncAt * (size_t)m->maxClusters * 64, m->dSync,
+                               (size_t)nClusters * 64 * sizeof(unsigned), hipMemcpyDeviceToHost, m->stream));
+        ++syncAt;
       }
     } else {
       hipLaunchKernelGGL(viterbi_fill_kernel, dim3(nB), dim3(kFillThreads), ldsBytes, m->stream, d, d_bases,
-                         (const uint64_t*)m->dReadOff, (const int32_t*)(m->dBatchRead + s),
-                         (const uint64_t*)(m->dSlotOff + s), m->arena, d_out_loglike, m->dRounds, maskWords);
+                         (const uint64_t*)m->dReadOff, batchRead, slots, m->arena, d_out_loglike, m->dRounds, maskWords, colRange);
       HIP_TRY(hipGetLastError());
     }
+    return DNAS_OK;
+  };
+
+  // ---- the groups of the bounded-memory decode, everything in order on m->stream
+  if (nGroups && m->tier >= 1 && !m->fillSeg) {
+    try {
+      const std::vector<char> code = dnas::jitCompile(m->jitDefs + "\n-DDNAS_SEGMENTS=1", m->plan.key + "+segments");
+      if (hipModuleLoadData(&m->moduleSeg, code.data()) != hipSuccess ||
+          hipModuleGetFunction(&m->fillSeg, m->moduleSeg, "viterbi_fill_tiera") != hipSuccess)
+        throw std::runtime_error("hipModuleLoadData/GetFunction failed");
+    } catch (const std::exception& e) {
+      m->fillSeg = nullptr;
+      return dnas::fail(DNAS_E_DEVICE, std::string("bounded-memory decode: the segment kernel is unavailable: ") + e.what());
     }
-    HIP_TRY(hipEventRecord(m->events[4 * b + 1], m->stream));
+  }
+  if (nGroups) {
+    // per group and segment: the column range and the (virtual) lattice origin of every read
+    std::vector<int> ranges(2 * ckTab);
+    std::vector<uint64_t> segSlot(ckTab);
+    for (const CkGroup& g : groups)
+      for (int64_t sg = 0; sg < g.nSeg; ++sg)
+        for (int64_t j = 0; j < g.n; ++j) {
+          const size_t at = g.tabAt + (size_t)sg * (size_t)g.n + (size_t)j;
+          const int64_t L = lenOf(g.first + j), c0 = sg * g.C;
+          ranges[2 * at] = (int)c0;
+          ranges[2 * at + 1] = (int)std::min(L, c0 + g.C - 1);
+          // column c of the segment sits at work(j) + (c - c0 + H) columns: the origin the kernels add c * column to
+          segSlot[at] = (uint64_t)((size_t)j * g.workStride + H * colDoubles) - (uint64_t)((size_t)c0 * colDoubles);
+        }
+    if (m->dColRange) { (void)hipFree(m->dColRange); (void)hipFree(m->dSegSlot); (void)hipFree(m->dWalks); }
+    m->dColRange = nullptr; m->dSegSlot = nullptr; m->dWalks = nullptr;
+    HIP_TRY(hipMalloc((void**)&m->dColRange, ranges.size() * sizeof(int)));
+    HIP_TRY(hipMalloc((void**)&m->dSegSlot, segSlot.size() * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc((void**)&m->dWalks, (size_t)nCk * sizeof(TracebackWalk)));
+    HIP_TRY(hipMemcpy(m->dColRange, ranges.data(), ranges.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m->dSegSlot, segSlot.data(), segSlot.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(m->dWalks, 0, (size_t)nCk * sizeof(TracebackWalk)));
+    const size_t headDoubles = (H + 1) * colDoubles;
+    for (size_t gi = 0; gi < nGroups; ++gi) {
+      const CkGroup& g = groups[gi];
+      RoctxRange groupRange("viterbi bounded-memory group");
+      double* const work = m->arena;
+      double* const ckpt = m->arena + (size_t)g.n * g.workStride;
+      // reads of the group that reach segment sg (sorted longest first: a prefix)
+      auto reach = [&](int64_t sg) {
+        int64_t k = 0;
+        while (k < g.n && lenOf(g.first + k) >= sg * g.C) ++k;
+        return (int)k;
+      };
+      auto copyRows = [&](double* dst, size_t dstStride, const double* src, size_t srcStride, int rows) -> int {
+        hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)std::min<size_t>((headDoubles + 255) / 256, 256), (unsigned)rows), dim3(256), 0,
+                           m->stream, dst, src, dstStride, srcStride, headDoubles);
+        HIP_TRY(hipGetLastError());
+        return DNAS_OK;
+      };
+      int rcl;
+      HIP_TRY(hipEventRecord(m->events[4 * gi], m->stream));
+      for (int64_t sg = 0; sg < g.nSeg; ++sg) {            // pass 1
+        const int nAct = reach(sg);
+        if (nAct == 0) break;
+        if (sg > 0) {
+          // the last H columns of the segment before and the hand-over lane behind them: kept, and moved to the front
+          if ((rcl = copyRows(ckpt + (size_t)sg * headDoubles, g.ckStride, work + (size_t)g.C * colDoubles, g.workStride, nAct)) != DNAS_OK) return rcl;
+          if ((rcl = copyRows(work, g.workStride, ckpt + (size_t)sg * headDoubles, g.ckStride, nAct)) != DNAS_OK) return rcl;
+        }
+        const size_t at = g.tabAt + (size_t)sg * (size_t)g.n;
+        if ((rcl = launchFill(m->dBatchRead + g.first, m->dSegSlot + at, nAct, m->dColRange + 2 * at)) != DNAS_OK) return rcl;
+      }
+      HIP_TRY(hipEventRecord(m->events[4 * gi + 1], m->stream));
+      HIP_TRY(hipEventRecord(m->events[4 * gi + 2], m->stream));
+      for (int64_t sg = g.nSeg - 1; sg >= 0; --sg) {        // pass 2
+        const int nAct = reach(sg), nAgain = sg + 1 < g.nSeg ? reach(sg + 1) : 0;
+        if (nAct == 0) continue;
+        const size_t at = g.tabAt + (size_t)sg * (size_t)g.n;
+        if (nAgain > 0) {
+          if (sg > 0 && (rcl = copyRows(work, g.workStride, ckpt + (size_t)sg * headDoubles, g.ckStride, nAgain)) != DNAS_OK) return rcl;
+          if ((rcl = launchFill(m->dBatchRead + g.first, m->dSegSlot + at, nAgain, m->dColRange + 2 * at)) != DNAS_OK) return rcl;
+        }
+        hipLaunchKernelGGL(viterbi_traceback_wave_kernel, dim3((nAct + 3) / 4), dim3(256), 0, m->stream, d, d_bases,
+                           (const uint64_t*)m->dReadOff, (const int32_t*)(m->dBatchRead + g.first), (const uint64_t*)(m->dSegSlot + at),
+                           (const double*)m->arena, d_out_sym, (const uint64_t*)m->dOutOff, d_out_len, d_out_status, nAct, m->dEvents,
+                           (const uint64_t*)m->dEvOff, m->dEvLen, (const int*)(m->dColRange + 2 * at), m->dWalks + g.first);
+        HIP_TRY(hipGetLastError());
+      }
+      HIP_TRY(hipEventRecord(m->events[4 * gi + 3], m->stream));
+    }
+  }
+
+  for (size_t b = 0; b < nBatches; ++b) {
+    const int64_t s = batchStart[b];
+    const int nB = (int)(batchStart[b + 1] - s);
+    const size_t ev = 4 * (nGroups + b);
+    // the half this batch fills was last read by the traceback of batch b-2
+    if (b >= 2) HIP_TRY(hipStreamWaitEvent(m->stream, m->sync[2 * (b - 2) + 1], 0));
+    HIP_TRY(hipEventRecord(m->events[ev], m->stream));
+    { const int rcl = launchFill(m->dBatchRead + s, m->dSlotOff + s, nB, nullptr); if (rcl != DNAS_OK) return rcl; }
+    HIP_TRY(hipEventRecord(m->events[ev + 1], m->stream));
     HIP_TRY(hipEventRecord(m->sync[2 * b], m->stream));
     RoctxRange tbRange("viterbi traceback");
     HIP_TRY(hipStreamWaitEvent(m->stream2, m->sync[2 * b], 0));
-    HIP_TRY(hipEventRecord(m->events[4 * b + 2], m->stream2));
+    HIP_TRY(hipEventRecord(m->events[ev + 2], m->stream2));
     // one wave per read finishes a read 4-5x sooner but costs about three times the CU time: for batches small enough
     // that the traceback is what the caller waits for (tier C, short jobs); large batches trace back thread-per-read on
     // two CUs, hidden behind the next batch's fill -- except the last batch of a call, which has the GPU to itself
@@ -614,22 +791,23 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
       hipLaunchKernelGGL(viterbi_traceback_wave_kernel, dim3((nB + 3) / 4), dim3(256), 0, m->stream2, d, d_bases,
                          (const uint64_t*)m->dReadOff, (const int32_t*)(m->dBatchRead + s), (const uint64_t*)(m->dSlotOff + s),
                          (const double*)m->arena, d_out_sym, (const uint64_t*)m->dOutOff, d_out_len, d_out_status, nB, m->dEvents,
-                         (const uint64_t*)m->dEvOff, m->dEvLen);
+                         (const uint64_t*)m->dEvOff, m->dEvLen, (const int*)nullptr, (TracebackWalk*)nullptr);
     else
     hipLaunchKernelGGL(viterbi_traceback_kernel, dim3((nB + kTraceThreads - 1) / kTraceThreads), dim3(kTraceThreads), 0,
                        m->stream2, d, d_bases, (const uint64_t*)m->dReadOff, (const int32_t*)(m->dBatchRead + s),
                        (const uint64_t*)(m->dSlotOff + s), (const double*)m->arena, d_out_sym,
                        (const uint64_t*)m->dOutOff, d_out_len, d_out_status, nB, m->dEvents, (const uint64_t*)m->dEvOff, m->dEvLen);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(m->events[4 * b + 3], m->stream2));
+    HIP_TRY(hipEventRecord(m->events[ev + 3], m->stream2));
     HIP_TRY(hipEventRecord(m->sync[2 * b + 1], m->stream2));
   }
   // trim so collect_stats sees exactly this call's events
-  while (m->events.size() > 4 * nBatches) {
+  while (m->events.size() > 4 * nTimed) {
     (void)hipEventDestroy(m->events.back());
     m->events.pop_back();
   }
-  m->stats.fill_launches = (int64_t)nBatches;
+  m->stats.fill_launches = (int64_t)fillLaunches;
+  m->stats.checkpointed_reads = nCk;
   m->stats.columns = columns;
   m->stats.lattice_bytes = (int64_t)(8 * lanes * (size_t)d.N) * columns;
   m->statsPending = true;
@@ -700,6 +878,8 @@ extern "C" int dnas_model_read_lattice(dnas_model* m, int64_t slot, int64_t len,
   for (; pos < m->lastBatchRead.size(); ++pos)
     if (m->lastBatchRead[pos] == (int32_t)slot) break;
   if (pos == m->lastBatchRead.size()) return dnas::fail(DNAS_E_INVALID, "no such read in the last call");
+  if ((int64_t)pos < m->lastCheckpointed)
+    return dnas::fail(DNAS_E_INVALID, "dnas_model_read_lattice: that read was decoded in segments (bounded-memory decode); its lattice was never whole");
   {
     size_t batchOf = 0;
     while (batchOf + 1 < m->lastBatchStart.size() && (int64_t)pos >= m->lastBatchStart[batchOf + 1]) ++batchOf;

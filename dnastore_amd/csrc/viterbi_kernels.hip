@@ -120,6 +120,15 @@ extern "C" __global__ void fill_neginf_kernel(double* __restrict__ p, size_t n) 
   if (i < n) p[i] = kNegInf;
 }
 
+// Bounded-memory decode: `n` doubles from src + row * srcStride to dst + row * dstStride for every row (one row per read
+// of the group).  grid = (chunks, rows).
+extern "C" __global__ void copy_rows_kernel(double* __restrict__ dst, const double* __restrict__ src, size_t dstStride,
+                                            size_t srcStride, size_t n) {
+  const double* s = src + (size_t)blockIdx.y * srcStride;
+  double* d = dst + (size_t)blockIdx.y * dstStride;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = s[i];
+}
+
 // Test/diagnostic aid: the full (D+2)-lane lattice of one read in reference state order,
 // out[(pos*(D+2)+lane)*N + state], whatever the storage tier.  grid = L+1, any block size.
 extern "C" __global__ void expand_lattice_kernel(DevModel m, const uint8_t* __restrict__ seq, const double* __restrict__ lat,
@@ -151,7 +160,8 @@ extern "C" __global__ void __launch_bounds__(kFillThreads)
 viterbi_fill_kernel(DevModel m, const uint8_t* __restrict__ bases, const uint64_t* __restrict__ readOff,
                     const int32_t* __restrict__ batchRead, const uint64_t* __restrict__ slotOff,
                     double* __restrict__ arena, double* __restrict__ outLoglike,
-                    unsigned long long* __restrict__ roundsTotal, int maskWords) {
+                    unsigned long long* __restrict__ roundsTotal, int maskWords,
+                    const int* __restrict__ colRange) {   // [reads][2] first and last column to fill (bounded-memory decode), or null: 0 .. L
   extern __shared__ unsigned ldsMask[];
   __shared__ double redBuf[kFillThreads / 64];
   const int tid = threadIdx.x;
@@ -170,7 +180,10 @@ viterbi_fill_kernel(DevModel m, const uint8_t* __restrict__ bases, const uint64_
   for (int w = tid; w < 2 * maskWords; w += T) ldsMask[w] = 0;
   __syncthreads();
 
-  for (int pos = 0; pos <= L; ++pos) {
+  // a segment c0 .. c1 of the read: the column before c0 is in the lattice (every lane is stored in this tier)
+  int c0 = 0, c1 = L;
+  if (colRange) { c0 = colRange[2 * blockIdx.x]; c1 = colRange[2 * blockIdx.x + 1]; }
+  for (int pos = c0; pos <= c1; ++pos) {
     double* col = lat + (size_t)pos * lanes * Npad;
     double* S = col;
     double* Dc = col + Npad;
@@ -241,6 +254,10 @@ viterbi_fill_kernel(DevModel m, const uint8_t* __restrict__ bases, const uint64_
     __syncthreads();
   }
 
+  if (c1 < L) {   // not the read's last segment: no log-likelihood yet
+    if (tid == 0) atomicAdd(roundsTotal, (unsigned long long)rounds);
+    return;
+  }
   // ---- local mode: loglike = best end state (viterbi.cpp:171-173)
   double* lastS = lat + (size_t)L * lanes * Npad;
   if (m.local) {
@@ -443,7 +460,11 @@ viterbi_traceback_wave_kernel(DevModel m, const uint8_t* __restrict__ bases, con
                               const double* __restrict__ arena, char* __restrict__ outSym,
                               const uint64_t* __restrict__ outOff, uint32_t* __restrict__ outLen,
                               uint8_t* __restrict__ outStatus, int nBatch,
-                              unsigned long long* __restrict__ events, const uint64_t* __restrict__ evOff, uint32_t* __restrict__ evLen) {
+                              unsigned long long* __restrict__ events, const uint64_t* __restrict__ evOff, uint32_t* __restrict__ evLen,
+                              const int* __restrict__ colRange, TracebackWalk* __restrict__ walks) {
+  // Bounded-memory decode (colRange / walks not null): the lattice holds columns colRange[2b] - (D + 1) .. colRange[2b + 1]
+  // of read b only.  The walk runs while it stands on a column >= colRange[2b] (a step looks at most D columns back), is
+  // then parked in walks[b] and picked up by the launch over the segment before.
   const int b = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
   const int ln = threadIdx.x & 63;
   if (b >= nBatch) return;
@@ -462,13 +483,22 @@ viterbi_traceback_wave_kernel(DevModel m, const uint8_t* __restrict__ bases, con
 #define WSLOT(st) (slotOf ? slotOf[st] : (st))
 #define WEVENT(type, p, payload) { if (ln == 0 && nEv < evCap) ev[nEv] = ((unsigned long long)(type) << 62) | ((unsigned long long)(unsigned)(p) << 32) | (unsigned long long)(payload); ++nEv; }
 
-  if (!(lattice_cell(m, lat, seq, N - 1, L, 0) > kNegInf)) {  // viterbi.cpp:198-201
-    if (ln == 0) { outLen[read] = 0; outStatus[read] = 1; }   // DNAS_READ_NO_PATH
-    return;
-  }
+  TracebackWalk* const walk = walks ? walks + b : nullptr;
+  const int stopBelow = colRange ? colRange[2 * b] : 0;
+  const int phase = walk ? walk->phase : 0;      // 0: not started, 1: parked, 2: finished
+  if (phase == 2) return;
   int state = N - 1, pos = L, mut = 0;
   uint8_t status = 0;
-  double curCell = lattice_cell(m, lat, seq, N - 1, L, 0);
+  double curCell = kNegInf;
+  if (phase == 1) {
+    state = walk->state; pos = walk->pos; mut = walk->mut; curCell = walk->curCell; n = (long)walk->n; nEv = (long)walk->nEv;
+  } else {
+    if (!(lattice_cell(m, lat, seq, N - 1, L, 0) > kNegInf)) {  // viterbi.cpp:198-201
+      if (ln == 0) { outLen[read] = 0; outStatus[read] = 1; if (walk) walk->phase = 2; }   // DNAS_READ_NO_PATH
+      return;
+    }
+    curCell = lattice_cell(m, lat, seq, N - 1, L, 0);
+  }
 
   // running best of a step (uniform over the wave)
   double best; bool found; int bState, bPos, bMut; double bCell; uint8_t bIn, bEm;
@@ -496,15 +526,17 @@ viterbi_traceback_wave_kernel(DevModel m, const uint8_t* __restrict__ bases, con
     state = bState; pos = bPos; mut = bMut; curCell = bCell; }
 
   do {
-    W_INIT();
-    if (m.local) {
-      for (int s0 = 0; s0 < N; s0 += 64) { const int st = s0 + ln; offer(st < N, st < N ? st : 0, st < N ? WSLOT(st) : 0, L, 0, 0., 0, 0); }
-    } else {
-      offer(ln == 0, N - 1, WSLOT(N - 1), L, 0, 0., 0, 0);
+    if (phase == 0) {
+      W_INIT();
+      if (m.local) {
+        for (int s0 = 0; s0 < N; s0 += 64) { const int st = s0 + ln; offer(st < N, st < N ? st : 0, st < N ? WSLOT(st) : 0, L, 0, 0., 0, 0); }
+      } else {
+        offer(ln == 0, N - 1, WSLOT(N - 1), L, 0, 0., 0, 0);
+      }
+      W_CHECK();
     }
-    W_CHECK();
 
-    while (pos >= 0 && state > 0) {
+    while (pos >= stopBelow && pos >= 0 && state > 0) {
       // round 1: what the step needs to know about the state, fetched by different lanes
       int meta = 0;
       if (ln == 0) meta = m.einPtr[state]; else if (ln == 1) meta = m.einPtr[state + 1];
@@ -596,6 +628,14 @@ viterbi_traceback_wave_kernel(DevModel m, const uint8_t* __restrict__ bases, con
 #undef W_CHECK
 #undef WSLOT
 
+  if (walk && status == 0 && pos >= 0 && state > 0) {   // the walk left this segment: park it
+    if (ln == 0) {
+      walk->state = state; walk->pos = pos; walk->mut = mut; walk->curCell = curCell; walk->n = (long long)n; walk->nEv = (long long)nEv;
+      walk->phase = 1;
+    }
+    return;
+  }
+  if (ln == 0 && walk) walk->phase = 2;
   if (ln == 0 && evLen) evLen[read] = (uint32_t)(nEv < evCap ? nEv : evCap);
 #undef WEVENT
   if (status == 0 && n > cap) status = 2;  // DNAS_READ_OUT_OVERFLOW

@@ -166,6 +166,9 @@ constexpr double kFresh = __builtin_huge_val();   // "not evaluated in this colu
 #ifndef DNAS_SLEEP
 #define DNAS_SLEEP 1   // idle waves poll the termination words every 64 * DNAS_SLEEP cycles
 #endif
+#ifndef DNAS_SEGMENTS
+#define DNAS_SEGMENTS 0   // 1: the launch fills a range of columns per read (bounded-memory decode), see colRange
+#endif
 #ifndef DNAS_NT_H
 #define DNAS_NT_H 1   // how many of the oldest history columns are streamed
 #endif
@@ -190,7 +193,8 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
                    double* __restrict__ arena, double* __restrict__ outLoglike,
                    unsigned long long* __restrict__ roundsTotal,
                    double* __restrict__ xbuf, unsigned* __restrict__ syncWords, const unsigned* __restrict__ foldTab,   // [G][GROWS][T]
-                   int nClusters, int nReads, unsigned long long timeoutTicks) {
+                   int nClusters, int nReads, unsigned long long timeoutTicks,
+                   const int* __restrict__ colRange) {   // [nReads][2] first and last column to fill, or null: 0 .. L
   extern __shared__ double lds[];
   extern __shared__ unsigned ldsU[];
   constexpr int T = DNAS_T, K = DNAS_K, D_ = DNAS_D, lanes = 2, NSm = DNAS_NS, NS = DNAS_NS * DNAS_G;   // stored lanes: S, D
@@ -302,6 +306,18 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
       }                                                                                          \
     });                                                                                          \
   }
+  // ... and come back from it when a read is resumed at a checkpoint (bounded-memory decode, runtime.hip)
+#define LOAD_LANE(p, lane, REG)                                                                  \
+  {                                                                                              \
+    const double* const colp = latM + ((size_t)(p) * lanes + (lane)) * NS;                       \
+    static_for<0, K / 2>([&](auto mc) {                                                          \
+      constexpr int m2 = mc.value;                                                               \
+      dbl2 v2;                                                                                   \
+      v2.x = kNegInf; v2.y = kNegInf;                                                            \
+      if (pairValid & (1u << m2)) v2 = reinterpret_cast<const dbl2*>(colp + (size_t)m2 * 2 * T)[tid]; \
+      REG[2 * m2] = v2.x; REG[2 * m2 + 1] = v2.y;                                                \
+    });                                                                                          \
+  }
   unsigned pairValid = 0;   // bit m: the lattice pair (rows 2m, 2m+1) of this thread holds a real state
   static_for<0, K / 2>([&](auto mc) {
     if ((META(2 * mc.value) | META(2 * mc.value + 1)) & 0x20000000u) pairValid |= 1u << mc.value;
@@ -351,7 +367,23 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
     if (member == 0 && tid == 0) xStore(xB, redOff, kNegInf);   // this read's reduction cell (last used two reads ago)
   }
 
-  for (int pos = 0; pos <= L && !aborted; ++pos) {
+  // Bounded-memory decode: this launch fills columns c0 .. c1 of the read only.  A segment that stops short of the read's
+  // end leaves, next to its last column, what the next column's phase A needs besides S(c1): the T1 hand-over, in the D
+  // lane of column c1 + 1 (which the launch that resumes there overwrites with the real D lane afterwards).
+  // Only the kernel built with -DDNAS_SEGMENTS=1 knows about segments: the one that fills whole reads stays as lean as it was.
+#if DNAS_SEGMENTS
+  int c0 = 0, c1 = L;
+  if (colRange) { c0 = colRange[2 * r]; c1 = colRange[2 * r + 1]; }
+  if (c0 > 0) {
+    LOAD_LANE(c0 - 1, 0, S)
+    LOAD_LANE(c0, 1, Dv)
+  }
+#else
+  constexpr int c0 = 0;
+  const int c1 = L;
+#endif
+
+  for (int pos = c0; pos <= c1 && !aborted; ++pos) {
     double* const col = latM + (size_t)pos * lanes * NS;
     const int x = pos > 0 ? seq[pos - 1] : 0;
     ++colSeq;
@@ -751,6 +783,13 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
     STAMP(tC)
   }
   if (aborted) break;
+#if DNAS_SEGMENTS
+  if (c1 < L) {                // a segment: park the hand-over, no log-likelihood yet
+    STORE_LANE(c1 + 1, 1, Dv)
+    if constexpr (G_ > 1) { r += rStep; continue; }
+    else break;
+  }
+#endif
 #ifdef DNAS_STAMP
   if (tid == 0 && blockIdx.x == 0) { roundsTotal[1] = tA; roundsTotal[2] = tP; roundsTotal[3] = tB; roundsTotal[4] = tC; roundsTotal[5] = (unsigned long long)rounds; roundsTotal[6] = tX; roundsTotal[7] = tW; }
 #endif

@@ -59,7 +59,8 @@ class FbStatsC(ctypes.Structure):
 
 class BatchStatsC(ctypes.Structure):
     _fields_ = [("fill_ms", ctypes.c_double), ("traceback_ms", ctypes.c_double), ("fill_launches", ctypes.c_int64),
-                ("columns", ctypes.c_int64), ("lattice_bytes", ctypes.c_int64), ("rounds", ctypes.c_int64)]
+                ("columns", ctypes.c_int64), ("lattice_bytes", ctypes.c_int64), ("rounds", ctypes.c_int64),
+                ("checkpointed_reads", ctypes.c_int64)]
 
 
 def declared_symbols():

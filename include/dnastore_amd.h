@@ -206,6 +206,7 @@ typedef struct dnas_batch_stats {
   int64_t fill_launches, columns; /* launches; sum over reads of L+1  */
   int64_t lattice_bytes;          /* 8*(D+2)*N*columns (algorithmic)  */
   int64_t rounds;                 /* relaxation rounds, summed        */
+  int64_t checkpointed_reads;     /* reads decoded in segments (bounded-memory decode: option checkpoint=) */
 } dnas_batch_stats;
 int dnas_model_last_stats(const dnas_model *model, dnas_batch_stats *out);
 
