@@ -74,7 +74,7 @@ struct dnas_model {
   int tier = 0;                 // 1 = tier A (register/LDS-resident JIT kernel, one work-group per read), 2 = tier C (the same
                                 // kernel, a cluster of work-groups per read), 0 = tier B (global-memory kernel)
   // bounded-memory decode: reads whose lattice does not fit the arena (checkpoint=auto), or every read (always), are
-  // filled in segments of `segmentCols` columns (0: chosen from the arena) from checkpoints, twice -- see DESIGN.md 3.6
+  // filled in segments of `segmentCols` columns (0: chosen from the arena) from checkpoints, twice -- see DESIGN.md 3.7
   int checkpointMode = 0;       // 0 auto, 1 always, 2 never
   int segmentCols = 0;
   int64_t lastCheckpointed = 0; // reads (in sorted order: the longest) of the last call that went that way
@@ -209,7 +209,7 @@ extern "C" int dnas_model_create(const dnas_flat_model* fm, int device_id, size_
 }
 
 // options: "key=value,key=value"; keys tier (A|B|C), cluster (work-groups per read), threads (512 | 1024 per work-group),
-// max_clusters, max_slots, cluster_timeout_s.  A key that is absent falls back to the environment variable DNAS_<KEY>.
+// max_clusters, max_slots, cluster_timeout_s, persistent, traceback, arena_fraction, checkpoint, segment.  A key that is absent falls back to the environment variable DNAS_<KEY>.
 extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, size_t arena_bytes, const char* options,
                                     dnas_model** out) {
   if (!fm || !out) return dnas::fail(DNAS_E_INVALID, "dnas_model_create: null argument");

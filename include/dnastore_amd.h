@@ -127,8 +127,11 @@ int dnas_model_create(const dnas_flat_model *fm, int device_id, size_t arena_byt
 /* The same with options, "key=value,key=value" (NULL: none).  Keys: tier = A | B | C (force a fill kernel; failing
  * to provide it is then an error), cluster = work-groups per read for tier C, threads = 512 | 1024 per work-group
  * (default 1024 for tier A; tier C takes 512 when the machine then fits fewer work-groups), max_clusters, max_slots (reads per
- * fill launch), cluster_timeout_s (tier C watchdog per lattice column).  A key that is absent falls back to the
- * environment variable DNAS_<KEY IN UPPER CASE>. */
+ * fill launch), cluster_timeout_s (tier C watchdog per lattice column), checkpoint = auto | always | never and
+ * segment = columns (bounded-memory decode of reads whose lattice -- the reference's ViterbiMatrix::cell,
+ * viterbi.h:48-50 -- does not fit the arena: segments of the lattice are filled from checkpoints and traced back one
+ * after the other; results are bit-identical), traceback = thread, persistent, arena_fraction.  A key that is absent
+ * falls back to the environment variable DNAS_<KEY IN UPPER CASE>. */
 int dnas_model_create_ex(const dnas_flat_model *fm, int device_id, size_t arena_bytes, const char *options,
                          dnas_model **out);
 void dnas_model_destroy(dnas_model *model);

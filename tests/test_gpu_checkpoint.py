@@ -1,4 +1,4 @@
-"""Bounded-memory decode (DESIGN.md 3.6): reads whose lattice does not fit the arena are filled in segments from
+"""Bounded-memory decode (DESIGN.md 3.7): reads whose lattice does not fit the arena are filled in segments from
 checkpoints and traced back segment by segment.  The reference keeps every read's whole lattice (viterbi.h:48-50) and
 therefore has no such path; what it must reproduce is the whole-lattice result, bit for bit: decoded symbols,
 log-likelihood, status and the traceback's event log, for every tier, both modes (local / --error-global), ragged
