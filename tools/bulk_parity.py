@@ -1,7 +1,8 @@
 """One-off confidence run: N reads of a bench workload decoded on the GPU and, in parallel on the host cores, by the
 CPU oracle; every decoded string and fp64 log-likelihood must be identical.
   python tools/bulk_parity.py 2000 14            (headline workload, configs[2])
-  python tools/bulk_parity.py 64 14 --config 1   (the 46 670-state composite, tier C)"""
+  python tools/bulk_parity.py 64 14 --config 1   (the 46 670-state composite, tier C)
+  python tools/bulk_parity.py 1000 14 --options checkpoint=always,segment=48   (the bounded-memory decode)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,6 +17,11 @@ def _oracle_chunk(args):
 
 
 if __name__ == "__main__":
+    options = None
+    if "--options" in sys.argv:
+        at = sys.argv.index("--options")
+        options = sys.argv[at + 1]
+        del sys.argv[at:at + 2]
     argv = [a for a in sys.argv[1:] if not a.startswith("--")]
     n = int(argv[0]) if len(argv) > 0 else 500
     workers = int(argv[1]) if len(argv) > 1 else 8
@@ -31,9 +37,9 @@ if __name__ == "__main__":
     t0 = time.time()
     with mp.get_context("spawn").Pool(workers) as pool:
         fut = pool.map_async(_oracle_chunk, [(mj, c) for c in chunks])
-        dec = da.ViterbiDecoder(m, da.MutatorParams.fromFlags(global_=True))
+        dec = da.ViterbiDecoder(m, da.MutatorParams.fromFlags(global_=True), options=options)
         out, ll, st = dec.decode(reads)
-        print("%s; %s" % (wl["name"], dec.tier[:60]))
+        print("%s; %s; options %s" % (wl["name"], dec.tier[:60], options))
         print("gpu done in %.1fs: %s" % (time.time() - t0, dec.stats()), flush=True)
         res = fut.get()
     bad = 0
