@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <numeric>
 #include <sstream>
@@ -126,6 +127,32 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T) {
     }
   }
 
+  // ---- forwarded runs (experimental: DNAS_PLAN_FWD=1, one work-group per read only).  A state whose ONLY in-edge comes
+  // from the state in the row right above it, in the same thread, needs no LDS accumulator, no read and no idle check: its
+  // cells are a function of that thread's registers ("F rows" of the program; the kernel evaluates them from S and D of
+  // the row above).  Candidates: the first such child of every state along the depth-first walk, in runs of at most maxRun
+  // states; the dealing below decides which of them really end up under their parent (a run needs a segment of the
+  // program long enough).  Measured on s16h74l4c4 (7 of 14 rows become F rows, 5 700 states sit under their parent): bit
+  // exact, but 0.44 of the roofline against 0.53 -- the heads are left with 7 rows to run down (18.7 sweeps per column
+  // instead of 14.4) and a sweep costs the same (3.5 k cycles against 3.3 k): it is bound by the rows that grow, not by the
+  // LDS round trips of the rows that do not.  Off unless asked for.
+  int maxRun = 3;
+  if (const char* e = getenv("DNAS_PLAN_RUN")) maxRun = std::max(1, std::min(4, atoi(e)));
+  bool useFwd = false;
+  if (const char* e = getenv("DNAS_PLAN_FWD")) useFwd = G == 1 && atoi(e) != 0;
+  if (!useFwd) maxRun = 1;
+  std::vector<int> candChild(N, -1), candParent(N, -1), candEdge(N, -1), runDepth(N, 0);
+  if (maxRun > 1)
+    for (int u : walk) {
+      if (runDepth[u] + 1 >= maxRun) continue;
+      for (int e : outOf[u]) {
+        const int c = edges[e].dst;
+        if (c == u || c == 0 || inOf[c].size() != 1 || parent[c] != u || candParent[c] >= 0) continue;
+        candChild[u] = c; candParent[c] = u; candEdge[c] = e; runDepth[c] = runDepth[u] + 1;
+        break;
+      }
+    }
+
   // ---- which member of the cluster owns which state.  A state with an in-edge from another member gets a slot in
   // its member's INBOX: cells of the cluster's exchange buffer that the other members offer into and that the
   // member folds into the state's LDS accumulators, slot r*T + t by thread t.
@@ -227,11 +254,13 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T) {
     typeOf[j] = it->second;
   }
   // deal the states of every member onto a program (caps per row) along the depth-first walk
-  auto deal = [&](const std::vector<Type>& caps, std::vector<int>* rows) -> bool {
+  // deal the states onto a program (caps per row; segLen[k]: the rows of the segment that J row k heads -- itself and the
+  // F rows below it --, 0 for an F row) along the depth-first walk.  att[c]: the state c really sits under (-1: none).
+  auto deal = [&](const std::vector<Type>& caps, const std::vector<int>& segLen, std::vector<int>* rows, std::vector<int>* att) -> bool {
     std::vector<unsigned> admits(types.size(), 0), own(types.size(), 0);
     for (size_t t = 0; t < types.size(); ++t)
       for (int k = 0; k < K; ++k)
-        if (types[t][0] <= caps[k][0] && types[t][1] <= caps[k][1] && types[t][2] <= caps[k][2] && ((caps[k][3] >> types[t][3]) & 1) &&
+        if (segLen[k] >= 1 && types[t][0] <= caps[k][0] && types[t][1] <= caps[k][1] && types[t][2] <= caps[k][2] && ((caps[k][3] >> types[t][3]) & 1) &&
             (types[t][4] == 0 || caps[k][4] >= 1)) {
           // caps[k][4]: 0 no state that offers into another member, 1 any state, 2 a row reserved for such states
           admits[t] |= 1u << k;
@@ -239,7 +268,15 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T) {
           const bool reserved = caps[k][4] == 2;
           if (reserved ? types[t][4] == 1 : types[t][1] == caps[k][1]) own[t] |= 1u << k;
         }
+    unsigned segAtLeast[6] = {0, 0, 0, 0, 0, 0}, segExactly[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < K; ++k)
+      for (int L = 1; L <= 5; ++L) {
+        if (segLen[k] >= L) segAtLeast[L] |= 1u << k;
+        if (segLen[k] == L) segExactly[L] |= 1u << k;
+      }
     rows->assign(N, -1);
+    att->assign(N, -1);
+    std::vector<char> hasUnder(N, 0);      // a state sits under this one
     for (int g = 0; g < G; ++g) {
       std::vector<std::vector<int>> members(K);
       unsigned freeRows = (1u << K) - 1u;
@@ -248,50 +285,78 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T) {
         members[k].push_back(j);
         if ((int)members[k].size() == T) freeRows &= ~(1u << k);
       };
-      auto pick = [&](int j, unsigned exclude) -> int {
-        unsigned avail = own[typeOf[j]] & freeRows & ~exclude;
-        if (!avail) avail = admits[typeOf[j]] & freeRows & ~exclude;
-        if (!avail) return -1;
+      auto pick = [&](int j, unsigned exclude, int need) -> int {
         const int par = parent[j];
         // (pair sweeps: the kernel reads the accumulators of rows 2m and 2m+1 together, so a chain runs along rows of
         //  one parity)
         const int start = (par >= 0 && (*rows)[par] >= 0) ? (*rows)[par] + (pairSweep ? 2 : 1) : 0;
-        const unsigned fw = start < 32 ? avail & ~((1u << start) - 1u) : 0u;
-        return __builtin_ctz(fw ? fw : avail);
+        const unsigned base = freeRows & ~exclude;
+        const unsigned sets[4] = {own[typeOf[j]] & segExactly[need], own[typeOf[j]] & segAtLeast[need], admits[typeOf[j]] & segExactly[need],
+                                  admits[typeOf[j]] & segAtLeast[need]};
+        for (unsigned set : sets) {
+          const unsigned avail = set & base;
+          if (!avail) continue;
+          const unsigned fw = start < 32 ? avail & ~((1u << start) - 1u) : 0u;
+          return __builtin_ctz(fw ? fw : avail);
+        }
+        return -1;
       };
       for (int j : walkOf[g]) {
-        int k = pick(j, 0u);
+        if ((*rows)[j] >= 0) continue;          // sits under its parent already
+        int run[5], L = 1;
+        run[0] = j;
+        for (int c = candChild[j]; c >= 0 && L < maxRun; c = candChild[c]) run[L++] = c;
+        int k = -1;
+        for (; L >= 1; --L) {
+          k = pick(j, 0u, L);
+          if (k >= 0) break;
+        }
         if (k < 0) {
+          L = 1;
           // every row that admits j is full: move a more flexible resident of one of them elsewhere
           bool moved = false;
           for (int r = 0; r < K && !moved; ++r) {
             if (!(admits[typeOf[j]] >> r & 1u)) continue;
             for (size_t m = 0; m < members[r].size(); ++m) {
               const int i = members[r][m];
+              if (hasUnder[i] || (*att)[i] >= 0) continue;          // (runs stay where they are)
               if (!(admits[typeOf[i]] & freeRows & ~(1u << r))) continue;
               members[r].erase(members[r].begin() + (long)m);
               freeRows |= 1u << r;
               (*rows)[i] = -1;
-              put(i, pick(i, 1u << r));
+              put(i, pick(i, 1u << r, 1));
               moved = true;
               break;
             }
           }
           if (!moved) return false;
-          k = pick(j, 0u);
+          k = pick(j, 0u, 1);
           if (k < 0) return false;
         }
         put(j, k);
+        for (int i = 1; i < L; ++i) {
+          (*rows)[run[i]] = k + i;
+          members[k + i].push_back(run[i]);
+          (*att)[run[i]] = run[i - 1];
+          hasUnder[run[i - 1]] = 1;
+        }
       }
     }
     return true;
   };
-  auto score = [&](const std::vector<int>& rows, int* readsOut, int* backOut, int* entriesOut) -> double {
+  auto score = [&](const std::vector<int>& rows, const std::vector<int>& att, int* readsOut, int* backOut, int* entriesOut) -> double {
+    std::vector<char> under(N, 0);
+    for (int j = 0; j < N; ++j) if (att[j] >= 0) under[att[j]] = 1;
     std::vector<Type> shape(K, Type{0, 0, 0, 0, 0});
-    for (int j = 0; j < N; ++j)
-      for (int q = 0; q < 3; ++q) shape[rows[j]][q] = std::max(shape[rows[j]][q], type[j][q]);
-    std::vector<char> inUse(K, 0);
-    for (int j = 0; j < N; ++j) inUse[rows[j]] = 1;
+    std::vector<char> inUse(K, 0), isFRow(K, 0);
+    for (int j = 0; j < N; ++j) {
+      const int k = rows[j];
+      inUse[k] = 1;
+      if (att[j] >= 0) isFRow[k] = 1;
+      shape[k][0] = std::max(shape[k][0], type[j][0] - (under[j] ? 1 : 0));
+      if (att[j] < 0) shape[k][1] = std::max(shape[k][1], type[j][1]);
+      shape[k][2] = std::max(shape[k][2], type[j][2]);
+    }
     int reads = 0, entries = 0;
     double offerCost = 0;   // in units of one fully decoded entry
     for (int k = 0; k < K; ++k)
@@ -299,7 +364,8 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T) {
         int clsMask = 0;
         for (int j = 0; j < N; ++j) if (rows[j] == k && type[j][3] != 7) clsMask |= 1 << type[j][3];
         const bool oneClass = clsMask != 0 && (clsMask & (clsMask - 1)) == 0 && clsMask < 16;
-        reads += 1 + shape[k][1]; entries += shape[k][0];
+        if (!isFRow[k]) reads += 1 + shape[k][1];
+        entries += shape[k][0];
         offerCost += !shape[k][2] ? 0.25 * shape[k][0] : (oneClass ? 0.55 * shape[k][0] : shape[k][0]);
       }
     std::vector<int> f(N, 0), g(N);
@@ -321,53 +387,59 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T) {
   };
   auto ldsNeed = [&](int nS) { return (size_t)(p.NSm + nS * T + 8 + 28 + T / 64 + (T / 64 + 2) / 2 + 1 + 2) * sizeof(double); };
 
-  std::vector<int> rowOfState;
+  std::vector<int> rowOfState, attOf(N, -1), segOfRow(K, 1);
   std::vector<Type> bestCaps;
+  double bestScore = -1;
+  std::string why = "no row program fits";
+  // out-degrees in ascending order, per kind, for the quantile shapes (of the largest member: the others fit below it)
+  std::vector<int> outS, outP, outPlainP;   // outPlainP: plain states without null in-edges
   {
-    // out-degrees in ascending order, per kind, for the quantile shapes (of the largest member: the others fit below it)
-    std::vector<int> outS, outP, outPlainP;   // outPlainP: plain states without null in-edges
-    {
-      std::vector<std::vector<int>> oS(G), oP(G), oPP(G);
-      for (int j = 0; j < N; ++j) {
-        (type[j][1] ? oS : oP)[part[j]].push_back(type[j][0]);
-        if (!type[j][1] && !type[j][2]) oPP[part[j]].push_back(type[j][0]);
-      }
-      auto merge = [&](std::vector<std::vector<int>>& per, std::vector<int>* out, bool everyMember) {
-        // element i = the largest i-th smallest out-degree of any member: a row shaped for it serves every member;
-        // everyMember: only as many elements as the smallest member has (a census every member must meet)
-        size_t n = everyMember ? (size_t)-1 : 0;
-        for (auto& v : per) { std::sort(v.begin(), v.end()); n = everyMember ? std::min(n, v.size()) : std::max(n, v.size()); }
-        out->assign(n, 0);
-        for (size_t i = 0; i < n; ++i)
-          for (auto& v : per)
-            if (i < v.size()) (*out)[i] = std::max((*out)[i], v[i]);
-      };
-      merge(oS, &outS, false);
-      merge(oP, &outP, false);
-      merge(oPP, &outPlainP, true);
+    std::vector<std::vector<int>> oS(G), oP(G), oPP(G);
+    for (int j = 0; j < N; ++j) {
+      (type[j][1] ? oS : oP)[part[j]].push_back(type[j][0]);
+      if (!type[j][1] && !type[j][2]) oPP[part[j]].push_back(type[j][0]);
     }
-    const int minS = (nNullDestMax + T - 1) / T;
-    double bestScore = -1;
-    std::string why = "no row program fits";
-    long biggest = 0;
-    for (int g = 0; g < G; ++g) biggest = std::max(biggest, (long)walkOf[g].size());
+    auto merge = [&](std::vector<std::vector<int>>& per, std::vector<int>* out, bool everyMember) {
+      // element i = the largest i-th smallest out-degree of any member: a row shaped for it serves every member;
+      // everyMember: only as many elements as the smallest member has (a census every member must meet)
+      size_t n = everyMember ? (size_t)-1 : 0;
+      for (auto& v : per) { std::sort(v.begin(), v.end()); n = everyMember ? std::min(n, v.size()) : std::max(n, v.size()); }
+      out->assign(n, 0);
+      for (size_t i = 0; i < n; ++i)
+        for (auto& v : per)
+          if (i < v.size()) (*out)[i] = std::max((*out)[i], v[i]);
+    };
+    merge(oS, &outS, false);
+    merge(oP, &outP, false);
+    merge(oPP, &outPlainP, true);
+  }
+  long biggest = 0;
+  for (int g = 0; g < G; ++g) biggest = std::max(biggest, (long)walkOf[g].size());
+  // Candidate programs over one segment structure (segLen per row).  The S rows, plain rows, quantile caps ... are laid
+  // out over the J rows only ("virtual" rows v = 0 .. VK-1).
+  auto tryPrograms = [&](const std::vector<int>& segLen, int minS) {
+    std::vector<int> jRow;
+    for (int k = 0; k < K; ++k) if (segLen[k] >= 1) jRow.push_back(k);
+    const int VK = (int)jRow.size();
+    const bool hasF = VK < K;
+    int nRemoteRowsNow = nRemoteRows, nRemoteSRowsNow = nRemoteSRows;
     // K is even (lattice pairs); when the states fit K-1 rows the last one may stay empty and
     // costs nothing in a sweep -- tried both ways
     // (when the rows reserved for the states that offer into other members leave no program -- tiny machines cut into
     //  clusters -- every row may hold them instead)
-    for (int attempt = 0; attempt < 2 && bestScore < 0; ++attempt, nRemoteRows = nRemoteSRows = 0)
-    for (int KU = K; KU >= std::max(1, K - 1); --KU)
+    for (int attempt = 0; attempt < 2 && bestScore < 0; ++attempt, nRemoteRowsNow = nRemoteSRowsNow = 0)
+    for (int KU = VK; KU >= std::max(1, VK - (hasF ? 0 : 1)); --KU)
     for (int nS = minS; nS <= std::min(KU, minS + 2); ++nS) {
-      if (ldsNeed(nS + nRemoteSRows) > kTierALdsLimit) { why = "LDS working set " + std::to_string(ldsNeed(nS + nRemoteSRows)) + " B exceeds one CU"; continue; }
-      if ((long)KU * T < biggest) continue;
-      if (nS + nRemoteRows > KU) continue;
-      const int KUL = KU - nRemoteRows;                 // rows in front of them
+      if (ldsNeed(nS + nRemoteSRowsNow) > kTierALdsLimit) { why = "LDS working set " + std::to_string(ldsNeed(nS + nRemoteSRowsNow)) + " B exceeds one CU"; continue; }
+      if (!hasF && (long)KU * T < biggest) continue;
+      if (nS + nRemoteRowsNow > KU) continue;
+      const int KUL = KU - nRemoteRowsNow;                 // rows in front of them
       for (int groups = 1; groups <= std::max(1, std::min(3, nS)); ++groups) {
         for (int ascending = 0; ascending < 2; ++ascending)
         for (int plainRows = 0; plainRows < 2; ++plainRows)
         for (int typedS = 0; typedS < 2; ++typedS) {
           // kinds: the S rows in `groups` runs spread evenly over the program
-          std::vector<int> isS(K, 0);
+          std::vector<int> isS(VK, 0);
           for (int g = 0, left = nS; g < groups && nS > 0; ++g) {
             const int len = left / (groups - g);
             const int at = g * KUL / groups;
@@ -375,10 +447,10 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T) {
             left -= len;
           }
           if (std::accumulate(isS.begin(), isS.end(), 0) != nS) continue;   // runs collided
-          std::vector<Type> caps(K);
+          std::vector<Type> vcaps(VK);
           int seenS = 0, seenP = 0, nPlainRows = 0;
-          for (int k = 0; k < K; ++k) {
-            if (k >= KUL && k < KU) { caps[k] = Type{maxOut, k - KUL < nRemoteSRows ? 1 : 0, 1, 0xff, 2}; continue; }
+          for (int k = 0; k < VK; ++k) {
+            if (k >= KUL && k < KU) { vcaps[k] = Type{maxOut, k - KUL < nRemoteSRowsNow ? 1 : 0, 1, 0xff, 2}; continue; }
             const std::vector<int>& sorted = isS[k] ? outS : outP;
             int& seen = isS[k] ? seenS : seenP;
             int cap = maxOut;
@@ -393,7 +465,7 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T) {
               const size_t have = (size_t)(std::upper_bound(outPlainP.begin(), outPlainP.end(), cap) - outPlainP.begin());
               if (have >= (size_t)(nPlainRows + 1) * T) { generic = 0; ++nPlainRows; }
             }
-            caps[k] = k < KU ? Type{cap, isS[k], generic, 0xff, nRemoteRows == 0 ? 1 : 0} : Type{-1, -1, -1, 0, -1};   // closed rows admit nothing
+            vcaps[k] = k < KU ? Type{cap, isS[k], generic, 0xff, nRemoteRowsNow == 0 ? 1 : 0} : Type{-1, -1, -1, 0, -1};   // closed rows admit nothing
             ++seen;
           }
           if (typedS && nS > 0) {
@@ -410,21 +482,26 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T) {
             size_t next = 0;
             for (int c : order) {
               const long need = (cnt[(size_t)c] + T - 1) / T;
-              for (long r = 0; r < need && next < sRows.size(); ++r) caps[sRows[next++]][3] = (1 << c) | (1 << 7);
+              for (long r = 0; r < need && next < sRows.size(); ++r) vcaps[sRows[next++]][3] = (1 << c) | (1 << 7);
             }
           }
-          std::vector<int> rows;
-          if (!deal(caps, &rows)) {
+          std::vector<Type> caps(K, Type{-1, -1, -1, 0, -1});     // F rows: closed to the dealing of heads
+          for (int v = 0; v < VK; ++v) caps[jRow[v]] = vcaps[v];
+          std::vector<int> rows, att;
+          if (!deal(caps, segLen, &rows, &att)) {
             if (getenv("DNAS_PLAN_DEBUG"))
-              fprintf(stderr, "plan candidate: rows %d S-rows %d groups %d ascending %d plain %d typedS %d -> states do not fit\n", KU, nS, groups,
+              fprintf(stderr, "plan candidate: rows %d (F rows %d) S-rows %d groups %d ascending %d plain %d typedS %d -> states do not fit\n", KU, K - VK, nS, groups,
                       ascending, plainRows, typedS);
             continue;
           }
           int reads = 0, back = 0, entries = 0;
-          const double sc = score(rows, &reads, &back, &entries);
-          if (getenv("DNAS_PLAN_DEBUG"))
-            fprintf(stderr, "plan candidate: rows %d S-rows %d groups %d ascending %d plain %d typedS %d -> reads %d entries %d back %d score %.0f\n", KU, nS,
+          const double sc = score(rows, att, &reads, &back, &entries);
+          if (getenv("DNAS_PLAN_DEBUG")) {
+            long nAtt = 0;
+            for (int v : att) nAtt += v >= 0;
+            fprintf(stderr, "plan candidate: rows %d (F rows %d, %ld states under their parent) S-rows %d groups %d ascending %d plain %d typedS %d -> reads %d entries %d back %d score %.0f\n", KU, K - VK, nAtt, nS,
                     groups, ascending, plainRows, typedS, reads, entries, back, sc);
+          }
           if (const char* pick = getenv("DNAS_PLAN_PICK")) {   // experiments: "rows,S-rows,groups,ascending"
             int a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
             if (sscanf(pick, "%d,%d,%d,%d,%d,%d", &a0, &a1, &a2, &a3, &a4, &a5) == 6 &&
@@ -432,23 +509,92 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T) {
           }
           if (entries > maxEntries) { why = "row shapes need " + std::to_string(entries) + " entry registers per thread"; continue; }
           if (bestScore < 0 || sc < bestScore) {
-            bestScore = sc; rowOfState = rows; bestCaps = caps;
+            bestScore = sc; rowOfState = rows; bestCaps = caps; attOf = att; segOfRow = segLen;
             p.sweepReads = reads; p.backEdgesOnWalk = back;
           }
         }
       }
     }
+  };
+  {
+    const int minS = (nNullDestMax + T - 1) / T;
+    // ---- with F rows: the segment structure from the census of candidate runs
+    if (maxRun > 1) {
+      std::vector<long> nRun(maxRun + 1, 0);
+      long nNullHeads = 0;
+      for (int j = 0; j < N; ++j)
+        if (candParent[j] < 0) {
+          int L = 1;
+          for (int c = candChild[j]; c >= 0; c = candChild[c]) ++L;
+          ++nRun[L];
+          nNullHeads += type[j][1];
+        }
+      // segments of L rows, L = maxRun .. 2, then lone rows: runs that find no segment of their length are cut
+      long bestFwd = -1;
+      std::vector<int> bestSegs;
+      const long cap = (long)T * 96 / 100;
+      std::vector<int> segs(maxRun + 1, 0);
+      std::function<void(int, int)> search = [&](int L, int rowsLeft) {
+        if (L == 1) {
+          segs[1] = rowsLeft;
+          std::vector<long> n(nRun);
+          long room = 0, fwd = 0, heads = 0, slots = 0;
+          for (int q = maxRun; q >= 2; --q) {
+            room += (long)segs[q] * cap;
+            const long placed = std::min(n[q], room);
+            room -= placed; fwd += placed * (q - 1); heads += placed;
+            n[q - 1] += n[q] - placed; n[1] += n[q] - placed;     // the rest is cut into q-1 and 1
+            slots += (long)segs[q];
+          }
+          heads += n[1];
+          slots += segs[1];
+          if (heads > slots * cap) return;
+          if (fwd > bestFwd) { bestFwd = fwd; bestSegs = segs; }
+          return;
+        }
+        for (int c = 0; c * L <= rowsLeft; ++c) { segs[L] = c; search(L - 1, rowsLeft - c * L); }
+      };
+      search(maxRun, K);
+      if (bestFwd > 0) {
+        // long segments first: a run's head follows its depth-first parent down the rows
+        std::vector<int> segLen(K, 0);
+        int k = 0;
+        for (int L = maxRun; L >= 1; --L)
+          for (int c = 0; c < bestSegs[L]; ++c) { segLen[k] = L; k += L; }
+        long nUnder = 0;
+        for (int j = 0; j < N; ++j) nUnder += candParent[j] >= 0 && type[j][1];
+        // states with null in-edges that end up under their parent need no S cell: fewer S rows may do
+        const int minSF = std::max(0, (int)((nNullDestMax - std::min(nUnder, bestFwd) * 7 / 10 + T - 1) / T));
+        if (getenv("DNAS_PLAN_DEBUG")) {
+          fprintf(stderr, "plan: runs of 1..%d:", maxRun);
+          for (int L = 1; L <= maxRun; ++L) fprintf(stderr, " %ld", nRun[L]);
+          fprintf(stderr, "; segments");
+          for (int L = maxRun; L >= 1; --L) fprintf(stderr, " %dx%d", bestSegs[L], L);
+          fprintf(stderr, "; up to %ld states under their parent; S rows from %d\n", bestFwd, minSF);
+        }
+        (void)nNullHeads;
+        tryPrograms(segLen, minSF);
+      }
+    }
+    if (bestScore < 0) tryPrograms(std::vector<int>(K, 1), minS);
     if (bestScore < 0) return no(why);
   }
 
   // A handful of odd states can spoil what the entries of a row have in common (its score class, emit /
   // null kind): move such minorities (at most 2 % of a row) to a row that admits them and is mixed anyway.
+  std::vector<char> hasUnder(N, 0);       // a state really sits under this one (its edge to it is no entry)
+  for (int j = 0; j < N; ++j) if (attOf[j] >= 0) hasUnder[attOf[j]] = 1;
+  // the out-edges that become entries: all but the one to the state underneath
+  std::vector<std::vector<int>> entOut(N);
+  for (int j = 0; j < N; ++j)
+    for (int e : outOf[j])
+      if (!(attOf[edges[e].dst] == j && candEdge[edges[e].dst] == e)) entOut[j].push_back(e);
   {
-    auto clsOf = [&](int j) { int c = -2; for (int e : outOf[j]) c = c == -2 ? edges[e].sc : (c == edges[e].sc ? c : -1); return c; };
-    auto kindOf = [&](int j) { int k = -1; for (int e : outOf[j]) { const int q = edges[e].isNull ? 2 : 1; k = k < 0 ? q : (k == q ? q : 0); } return k; };
+    auto clsOf = [&](int j) { int c = -2; for (int e : entOut[j]) c = c == -2 ? edges[e].sc : (c == edges[e].sc ? c : -1); return c; };
+    auto kindOf = [&](int j) { int k = -1; for (int e : entOut[j]) { const int q = edges[e].isNull ? 2 : 1; k = k < 0 ? q : (k == q ? q : 0); } return k; };
     auto rowEntries = [&]() {
       std::vector<int> nOut(K, 0);
-      for (int j = 0; j < N; ++j) nOut[rowOfState[j]] = std::max(nOut[rowOfState[j]], type[j][0]);
+      for (int j = 0; j < N; ++j) nOut[rowOfState[j]] = std::max(nOut[rowOfState[j]], (int)entOut[j].size());
       return nOut;
     };
     for (int attr = 0; attr < 2; ++attr) {
@@ -459,7 +605,7 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T) {
       auto common = [&](int k) {
         int c = -2;
         for (int j = 0; j < N; ++j)
-          if (rowOfState[j] == k && !outOf[j].empty()) {
+          if (rowOfState[j] == k && !entOut[j].empty()) {
             const int v = attr == 0 ? clsOf(j) : kindOf(j);
             c = c == -2 ? v : (c == v ? c : (attr == 0 ? -1 : 0));
           }
@@ -468,8 +614,8 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T) {
       for (int k = 0; k < K; ++k) {
         std::map<int, std::vector<int>> byVal;
         for (int j = 0; j < N; ++j)
-          if (rowOfState[j] == k && !outOf[j].empty()) byVal[attr == 0 ? clsOf(j) : kindOf(j)].push_back(j);
-        if (byVal.size() < 2) continue;
+          if (rowOfState[j] == k && !entOut[j].empty() && attOf[j] < 0 && !hasUnder[j]) byVal[attr == 0 ? clsOf(j) : kindOf(j)].push_back(j);
+        if (byVal.size() < 2 || segOfRow[k] != 1) continue;     // (rows of runs stay as dealt)
         size_t most = 0, total = 0;
         for (const auto& kv : byVal) { most = std::max(most, kv.second.size()); total += kv.second.size(); }
         if (total - most > (size_t)G * T / 50) continue;
@@ -477,10 +623,10 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T) {
           if (kv.second.size() == most) continue;
           for (int j : kv.second) {
             for (int k2 = 0; k2 < K; ++k2) {
-              if (k2 == k || fill[(size_t)part[j] * K + k2] >= T) continue;
+              if (k2 == k || segOfRow[k2] != 1 || fill[(size_t)part[j] * K + k2] >= T) continue;
               const Type& c2 = bestCaps[k2];
               if (type[j][0] > c2[0] || type[j][1] > c2[1] || type[j][2] > c2[2] || !((c2[3] >> type[j][3]) & 1) || (type[j][4] && c2[4] == 0) || (!type[j][4] && c2[4] == 2)) continue;
-              if (type[j][0] > nOutNow[k2]) continue;      // would grow the row's entry registers
+              if ((int)entOut[j].size() > nOutNow[k2]) continue;      // would grow the row's entry registers
               const int have = common(k2);
               const int mine = attr == 0 ? clsOf(j) : kindOf(j);
               if (!(have == (attr == 0 ? -1 : 0) || have == mine || have == -2)) continue;   // would spoil k2
@@ -521,6 +667,10 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T) {
       const std::vector<int>& mem = rowMembers[b];
       if (mem.empty()) continue;          // padding row
       const int n = (int)mem.size();
+      if (segOfRow[(int)(b % (size_t)K)] == 0) {          // an F row: every state sits in the lane of the state it hangs under
+        for (int j : mem) laneOf[j] = laneOf[attOf[j]];
+        continue;
+      }
       std::vector<char> lanesFree(T, 1);
       std::vector<int> newLane(n, -1), lead(n, -1);
       std::vector<std::array<unsigned char, 32>> bankUse(T / 32);   // per 32-lane half: leads per bank pair
@@ -559,34 +709,43 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T) {
   }
 
   // row shapes as used, S stripes
-  p.rows.assign(K, RowShape{0, -1, -1, -2, 0, -1});   // kind / cls / gOut: -1 / -2 / -1 = no entry seen yet
+  p.rows.assign(K, RowShape{0, -1, -1, -2, 0, -1, 0, -1, -2});   // kind / cls / gOut: -1 / -2 / -1 = no entry seen yet
   std::vector<int> needS(K, 0);
   long real = 0;
   for (int j = 0; j < N; ++j) {
     RowShape& r = p.rows[rowOfState[j]];
-    r.nOut = std::max(r.nOut, type[j][0]);
-    for (int e : outOf[j]) {
+    r.nOut = std::max(r.nOut, (int)entOut[j].size());
+    if (attOf[j] >= 0) {                      // what the edges from above have in common
+      const Edge& e = edges[candEdge[j]];
+      const int kind = e.isNull ? 2 : 1;
+      r.fkind = r.fkind < 0 ? kind : (r.fkind == kind ? kind : 0);
+      r.fcls = r.fcls == -2 ? e.sc : (r.fcls == e.sc ? r.fcls : -1);
+    }
+    for (int e : entOut[j]) {
       const int kind = edges[e].isNull ? 2 : 1;
       r.kind = r.kind < 0 ? kind : (r.kind == kind ? kind : 0);
       r.cls = r.cls == -2 ? edges[e].sc : (r.cls == edges[e].sc ? r.cls : -1);
       const int go = part[edges[e].dst] != part[j] ? 1 : 0;
       r.gOut = r.gOut < 0 ? go : (r.gOut == go ? go : 2);
     }
-    needS[rowOfState[j]] |= type[j][1];
-    real += type[j][0];
+    if (attOf[j] < 0) needS[rowOfState[j]] |= type[j][1];
+    real += (long)entOut[j].size();
   }
   p.nSRows = 0;
   for (int k = 0; k < K; ++k) if (needS[k]) p.rows[k].sIdx = p.nSRows++;
   std::vector<char> rowUsed(K, 0);
   for (int j = 0; j < N; ++j) rowUsed[rowOfState[j]] = 1;
   for (int k = 0; k < K; ++k) if (!rowUsed[k]) p.rows[k].nOut = -1;   // the kernel skips the row
-  for (RowShape& r : p.rows) { if (r.kind < 0) r.kind = 0; if (r.cls == -2) r.cls = -1; if (r.gOut < 0) r.gOut = 0; }
+  for (RowShape& r : p.rows) { if (r.kind < 0) r.kind = 0; if (r.cls == -2) r.cls = -1; if (r.gOut < 0) r.gOut = 0; if (r.fkind < 0) r.fkind = 0; if (r.fcls == -2) r.fcls = -1; }
+  p.nFwdRows = 0;
+  for (int k = 0; k < K; ++k) if (segOfRow[k] == 0 && rowUsed[k]) p.rows[k].fwd = ++p.nFwdRows;      // 1-based index among the F rows
+  for (int k = 0; k < K; ++k) if (segOfRow[k] == 0 && !rowUsed[k]) p.rows[k].nOut = -1;
   for (int k = 0; k < K; ++k) {
     bool full = true;
     for (int g = 0; g < G; ++g) {
       const std::vector<int>& mem = rowMembers[(size_t)g * K + k];
       full = full && (int)mem.size() == T;
-      for (int j : mem) full = full && type[j][0] == p.rows[k].nOut;
+      for (int j : mem) full = full && (int)entOut[j].size() == p.rows[k].nOut;
     }
     p.rows[k].full = full ? 1 : 0;
   }
@@ -617,8 +776,8 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T) {
   long fwd = 0, fwdSameWave = 0;
   for (int j = 0; j < N; ++j) {
     const int row = rowOfState[j], lane = laneOf[j];
-    for (size_t i = 0; i < outOf[j].size(); ++i) {
-      const Edge& e = edges[outOf[j][i]];
+    for (size_t i = 0; i < entOut[j].size(); ++i) {
+      const Edge& e = edges[entOut[j][i]];
       const int drow = rowOfState[e.dst], dlane = laneOf[e.dst];
       unsigned ent;
       if (part[e.dst] != part[j]) {
@@ -640,6 +799,19 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T) {
     }
   }
   p.sameWave = fwd ? (double)fwdSameWave / (double)fwd : 1.0;
+
+  // F rows: per lane, the edge from the state above -- bit 0 valid, bit 1 null edge, [2:4) score class, [4:6) emitted base;
+  // five rows to a 32-bit word (word (f-1)/5, bits 6*((f-1)%5) ...), f = the row's index among the F rows
+  p.nFwdWords = (p.nFwdRows + 4) / 5;
+  p.fwdTab.assign((size_t)std::max(p.nFwdWords, 1) * T, 0u);
+  for (int j = 0; j < N; ++j)
+    if (attOf[j] >= 0) {
+      const int row = rowOfState[j], f = p.rows[row].fwd - 1;
+      if (f < 0 || rowOfState[attOf[j]] != row - 1 || laneOf[attOf[j]] != laneOf[j]) return no("internal: a forwarded state is not under its parent");
+      const Edge& e = edges[candEdge[j]];
+      const unsigned bits = 1u | (e.isNull ? 2u : 0u) | ((unsigned)e.sc << 2) | ((unsigned)(e.base & 3) << 4);
+      p.fwdTab[(size_t)(f / 5) * T + laneOf[j]] |= bits << (6 * (f % 5));
+    }
 
   // fold table: inbox slot r*T + t of a member -> LDS cells of the state behind it: DC byte address >> 3 | SC byte
   // address >> 3 << 16 (0xffff: the state has no S cell); 0: slot unused
@@ -672,10 +844,10 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T) {
   for (int k = 0; k < K; ++k) {
     if (k) rows << ",";
     rows << "{" << p.rows[k].nOut << "," << p.rows[k].sIdx << "," << p.rows[k].kind << "," << p.rows[k].cls << "," << p.rows[k].full << ","
-         << p.rows[k].gOut << "}";
+         << p.rows[k].gOut << "," << p.rows[k].fwd << "," << p.rows[k].fkind << "," << p.rows[k].fcls << "}";
   }
   defs << "-DDNAS_T=" << T << "\n-DDNAS_K=" << K << "\n-DDNAS_D=" << D << "\n-DDNAS_NS=" << p.NSm << "\n-DDNAS_SROWS=" << p.nSRows
-       << "\n-DDNAS_NCLS=" << p.nClasses << "\n-DDNAS_G=" << G << "\n-DDNAS_GROWS=" << nInboxRows << "\n-DDNAS_GSROWS=" << nInboxSRows << "\n-DDNAS_PAIRSWEEP=" << (pairSweep ? 1 : 0) << "\n-DDNAS_ROWS=" << rows.str();
+       << "\n-DDNAS_NCLS=" << p.nClasses << "\n-DDNAS_G=" << G << "\n-DDNAS_GROWS=" << nInboxRows << "\n-DDNAS_GSROWS=" << nInboxSRows << "\n-DDNAS_PAIRSWEEP=" << (pairSweep ? 1 : 0) << "\n-DDNAS_FWDWORDS=" << p.nFwdWords << "\n-DDNAS_ROWS=" << rows.str();
   p.defines = defs.str();
   p.key = "T" + std::to_string(T) + "K" + std::to_string(K) + "D" + std::to_string(D) + "S" + std::to_string(p.nSRows) + "C" +
           std::to_string(p.nClasses) + "G" + std::to_string(G) + "X" + std::to_string(nInboxRows) + "x" + std::to_string(nInboxSRows) + (pairSweep ? "p" : "") + "R" + rows.str();

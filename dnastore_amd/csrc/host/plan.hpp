@@ -31,8 +31,11 @@ namespace dnas {
 // null in-edges), and what all entries of the row have in common, which the kernel then does not decode per
 // lane: kind 1 = emit edges only, 2 = null edges only, 0 = both; cls = the common score class or -1;
 // full = every lane of the row holds a state with exactly nOut out-edges (no entry is empty);
-// gOut = 0: every entry of the row points into LDS, 1: every entry into the exchange buffer, 2: mixed
-struct RowShape { int nOut, sIdx, kind, cls, full, gOut; };
+// gOut = 0: every entry of the row points into LDS, 1: every entry into the exchange buffer, 2: mixed;
+// fwd > 0: an "F row" (the fwd-th of the program): every state of the row has ONE in-edge, from the state in the row above in
+// the same thread, and is evaluated from that thread's registers -- no LDS cell, no entry on the parent's side; fkind / fcls:
+// what those edges have in common (1 emit, 2 null, 0 both; score class or -1)
+struct RowShape { int nOut, sIdx, kind, cls, full, gOut, fwd, fkind, fcls; };
 
 struct TierAPlan {
   bool ok = false;
@@ -52,6 +55,8 @@ struct TierAPlan {
   std::vector<uint32_t> entTab;   // [G][nEntries][T]  out-edges, see viterbi_tiera.hip
   std::vector<uint32_t> metaTab;  // [G][K][T]  mdl | ctx<<4 | flags
   std::vector<uint32_t> foldTab;  // [G][nGRows][T]  inbox slot -> LDS cells of its state (DC addr >> 3 | SC addr >> 3 << 16), 0: unused
+  int nFwdRows = 0, nFwdWords = 0;
+  std::vector<uint32_t> fwdTab;   // [nFwdWords][T]  F rows: the edge from the state above, 6 bits per row (plan.cpp)
   double score[4] = {0, 0, 0, 0};
   size_t ldsBytes = 0;
   double fillRatio = 0;           // real entries / padded entries

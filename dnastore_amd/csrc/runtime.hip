@@ -67,6 +67,7 @@ struct TierALaunch {
   int nReads;
   unsigned long long timeoutTicks;
   const int* colRange;          // bounded-memory decode: [nReads][2] first and last column of this launch (null: whole reads)
+  const unsigned* fwdTab;       // F rows of the program: the edge from the state above, per lane (plan.cpp)
 };
 
 struct dnas_model {
@@ -87,6 +88,7 @@ struct dnas_model {
   double* dXbuf = nullptr;      // tier C: exchange buffers, one per cluster
   unsigned* dSync = nullptr;    // tier C: sync blocks (64 u32 per cluster)
   unsigned* dFoldTab = nullptr; // tier C: inbox slot -> LDS cells, per member
+  unsigned* dFwdTab = nullptr;  // F rows of the row program
   size_t xStride = 0;           // doubles per cluster in dXbuf
   unsigned long long timeoutTicks = 0;
   std::vector<unsigned> syncCheck;   // host copies of the sync blocks of every launch of the last call (watchdog, placement census)
@@ -314,6 +316,8 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
           if (hipMalloc((void**)&m->dEntTab, p.entTab.size() * 4) != hipSuccess ||
               hipMalloc((void**)&m->dMetaTab, p.metaTab.size() * 4) != hipSuccess ||
               hipMalloc((void**)&m->dSlotOf, p.slotOf.size() * 4) != hipSuccess ||
+              hipMalloc((void**)&m->dFwdTab, std::max<size_t>(p.fwdTab.size(), 1) * 4) != hipSuccess ||
+              hipMemcpy(m->dFwdTab, p.fwdTab.data(), p.fwdTab.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
               hipMemcpy(m->dEntTab, p.entTab.data(), p.entTab.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
               hipMemcpy(m->dMetaTab, p.metaTab.data(), p.metaTab.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
               hipMemcpy(m->dSlotOf, p.slotOf.data(), p.slotOf.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
@@ -415,6 +419,7 @@ extern "C" void dnas_model_destroy(dnas_model* m) {
   if (m->dXbuf) (void)hipFree(m->dXbuf);
   if (m->dSync) (void)hipFree(m->dSync);
   if (m->dFoldTab) (void)hipFree(m->dFoldTab);
+  if (m->dFwdTab) (void)hipFree(m->dFwdTab);
   if (m->dEvents) (void)hipFree(m->dEvents);
   if (m->dEvOff) (void)hipFree(m->dEvOff);
   if (m->dEvLen) (void)hipFree(m->dEvLen);
@@ -648,7 +653,7 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
     RoctxRange fillRange(m->tier == 2 ? "viterbi fill (tier C)" : (m->tier == 1 ? "viterbi fill (tier A)" : "viterbi fill (tier B)"));
     if (m->tier >= 1) {
       TierALaunch la{m->argsA, m->dEntTab, m->dMetaTab, d_bases, m->dReadOff, batchRead, slots,
-                     m->arena, d_out_loglike, m->dRounds, nullptr, nullptr, nullptr, 0, nB, 0ull, colRange};
+                     m->arena, d_out_loglike, m->dRounds, nullptr, nullptr, nullptr, 0, nB, 0ull, colRange, m->dFwdTab};
       unsigned grid = (unsigned)nB;
       if (m->tier == 1 && m->persistentGroups > 0 && nB > m->persistentGroups && !colRange) {
         grid = (unsigned)m->persistentGroups;      // the work-groups pull the reads beyond the first `grid` from a queue
@@ -1022,6 +1027,27 @@ extern "C" int dnas_tierc_plan(const dnas_flat_model* fm, int32_t members, int32
 }
 
 // Tier C diagnostics of the last call: clusters that ran, and how many of them had members on more than one XCD.
+// Analysis / test aid: the F rows of the tier-A plan (rows whose states are evaluated from the registers of the row above).
+// fwd_rows[rows][3] = {index among the F rows (0: not an F row), kind of the edges from above (1 emit, 2 null, 0 both), their
+// common score class or -1}; fwd_tab[n_words][threads]: 6 bits per F row and lane (layout: csrc/host/plan.cpp).
+extern "C" int dnas_tiera_plan_forwarded(const dnas_flat_model* fm, int32_t* fwd_rows, uint32_t* fwd_tab, size_t fwd_cap, int32_t* n_words) {
+  if (!fm || !n_words) return dnas::fail(DNAS_E_INVALID, "null argument");
+  try {
+    const dnas::TierAPlan p = dnas::buildTierAPlan(*fm);
+    if (!p.ok) return dnas::fail(DNAS_E_UNSUPPORTED, p.whyNot);
+    *n_words = p.nFwdWords;
+    if (fwd_rows)
+      for (int k = 0; k < p.K; ++k) { fwd_rows[3 * k] = p.rows[k].fwd; fwd_rows[3 * k + 1] = p.rows[k].fkind; fwd_rows[3 * k + 2] = p.rows[k].fcls; }
+    if (fwd_tab) {
+      if (fwd_cap < (size_t)p.nFwdWords * p.T) return dnas::fail(DNAS_E_INVALID, "forward table buffer too small");
+      memcpy(fwd_tab, p.fwdTab.data(), (size_t)p.nFwdWords * p.T * sizeof(uint32_t));
+    }
+    return DNAS_OK;
+  } catch (const std::exception& e) {
+    return dnas::fail(DNAS_E_DEVICE, e.what());
+  }
+}
+
 extern "C" int dnas_model_cluster_census(dnas_model* m, int32_t* clusters, int32_t* split) {
   if (!m || !clusters || !split) return dnas::fail(DNAS_E_INVALID, "null argument");
   if (m->statsPending) return dnas::fail(DNAS_E_INVALID, "call dnas_model_sync first");

@@ -57,6 +57,27 @@ def test_full_lattice_bit_exact(da, oracle_mod, ref_data, mach, fa, flags):
     dec.close()
 
 
+def test_full_lattice_with_forwarded_rows(da, oracle_mod, ref_data, monkeypatch):
+    """DNAS_PLAN_FWD=1 (experimental): the row program with F rows -- states evaluated from the registers of the row above
+    instead of an LDS accumulator -- gives the same cells, bit for bit."""
+    O = oracle_mod
+    monkeypatch.setenv("DNAS_PLAN_FWD", "1")
+    for mach, fa, flags in [("s16h74l4c4.json", "hello.s16h74.del.fa", dict(global_=True)), ("s16h74l4c4.json", "hello.s16h74.del.fa", dict()),
+                            ("h74l4c4.json", "hello.h74.sub.fa", dict(global_=True))]:
+        path = os.path.join(ref_data, mach)
+        dec = da.ViterbiDecoder(da.Machine.fromFile(path), da.MutatorParams.fromFlags(**flags))
+        assert dec.tier.startswith("tier A")
+        orc = O.ViterbiOracle(O.Machine.from_file(path), O.MutatorParams.from_cli(**flags))
+        reads = [seq for _, seq in da.read_fastseqs(os.path.join(ref_data, fa))]
+        out, ll, st = dec.decode(reads)
+        for i, r in enumerate(reads):
+            s, oll, olat = orc.decode(r, want_lattice=True)
+            assert out[i] == s and ll[i] == oll
+            lat = np.ascontiguousarray(dec.lattice(i, len(r)).transpose(0, 2, 1))
+            assert np.array_equal(lat.view(np.uint64), olat.view(np.uint64))
+        dec.close()
+
+
 @pytest.mark.parametrize("flags,noise", [
     (dict(global_=True), dict(sub=0.01)),
     (dict(), dict(sub=0.02, dele=0.01, dup=0.01)),
