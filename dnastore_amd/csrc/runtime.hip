@@ -452,6 +452,281 @@ extern "C" int dnas_model_last_stats(const dnas_model* m, dnas_batch_stats* out)
   return DNAS_OK;
 }
 
+namespace {
+
+// ---- one call of dnas_viterbi_batch_device, planned on the host -----------------------------------------------------------
+// Bounded-memory decode (the reference holds every read's whole lattice, viterbi.h:48-50): the reads whose lattice does not
+// fit half the arena -- the longest, first in sorted order -- are decoded in groups, in segments of C columns:
+//   pass 1  fill segment after segment into a work buffer of H + C + 1 columns per read, keeping of every segment only its
+//           last H columns and the hand-over lane (what the fill of the next segment and a traceback step look back at)
+//   pass 2  from the last segment to the first: restore the checkpoint in front of the segment, fill it again (the last one
+//           is still there), and let the traceback walk it; a walk that leaves the segment is parked until the next launch
+// Fill work doubles; memory per read drops from L + 1 columns to about 2 sqrt((L + 1)(H + 1)).
+struct SegmentGroup {
+  int64_t first, n;          // reads [first, first + n) of the sorted order
+  int64_t C, nSeg;           // columns per segment, segments of the longest read
+  size_t workStride, ckStride;   // doubles per read: work buffer (H + C + 1 columns + a spare cell), checkpoint store
+  size_t tabAt;              // where the group's per-segment tables start (entries of n reads per segment)
+};
+struct CallPlan {
+  std::vector<int32_t> order;        // reads, longest first
+  std::vector<uint64_t> slotOff;     // lattice of read i of the sorted order inside its arena half
+  std::vector<int64_t> batchStart;   // whole-lattice batches: first read of each, + n_reads
+  std::vector<SegmentGroup> groups;  // reads [0, nSegmented) in groups
+  int64_t nSegmented = 0, columns = 0;
+  size_t peak = 0;                   // doubles of the largest batch
+  size_t groupPeak = 0, tabEntries = 0, groupLaunches = 0;
+};
+
+int plan_call(const dnas_model* m, int64_t n_reads, const uint64_t* read_offsets, CallPlan* cp) {
+  const DevModel& d = m->dm;
+  const size_t colDoubles = (size_t)d.storedLanes * (size_t)d.Npad;
+  // longest reads first: a batch's work-groups then finish together
+  cp->order.resize((size_t)n_reads);
+  std::iota(cp->order.begin(), cp->order.end(), 0);
+  std::stable_sort(cp->order.begin(), cp->order.end(), [&](int32_t a, int32_t b) {
+    return read_offsets[a + 1] - read_offsets[a] > read_offsets[b + 1] - read_offsets[b];
+  });
+  auto lenOf = [&](int64_t i) { return (int64_t)(read_offsets[cp->order[(size_t)i] + 1] - read_offsets[cp->order[(size_t)i]]); };
+  for (int64_t i = 0; i < n_reads; ++i)
+    if (lenOf(i) > 0x7ffffff0ll) return dnas::fail(DNAS_E_UNSUPPORTED, "read too long");
+  // two arena halves: batch i fills half (i & 1) while the traceback of batch i-1 still reads the other
+  const size_t arenaCapDoubles = m->arenaCap / sizeof(double) / 2;
+
+  // ---- the reads that go through segments, and their groups
+  const size_t H = (size_t)d.D + 1;
+  int64_t nSeg = 0;
+  if (m->checkpointMode == 1) nSeg = n_reads;
+  else if (m->checkpointMode == 0)
+    while (nSeg < n_reads && colDoubles * (size_t)(lenOf(nSeg) + 1) + 8 > arenaCapDoubles) ++nSeg;
+  cp->nSegmented = nSeg;
+  const size_t budget = m->arenaCap / sizeof(double);
+  const int64_t groupMax = m->tier == 2 ? m->maxClusters : m->maxSlots;
+  for (int64_t g0 = 0; g0 < nSeg;) {
+    const int64_t Lmax = lenOf(g0);
+    int64_t nG = std::min(nSeg - g0, groupMax), C = 0;
+    auto perRead = [&](int64_t c) {
+      return (H + (size_t)c + 1) * colDoubles + 8 + (size_t)(Lmax / c + 1) * (H + 1) * colDoubles;
+    };
+    const int64_t cMin = (int64_t)H + 1;
+    for (;;) {
+      const size_t per = budget / (size_t)nG;
+      if (m->segmentCols > 0) {
+        C = std::max<int64_t>(cMin, m->segmentCols);
+        if (perRead(C) <= per) break;
+      } else {
+        C = std::max<int64_t>(cMin, (int64_t)std::ceil(std::sqrt((double)(Lmax + 1) * (double)(H + 1))));
+        if (perRead(C) <= per) {
+          while (C < Lmax + 1 && perRead(std::min(2 * C, Lmax + 1)) <= per) C = std::min(2 * C, Lmax + 1);
+          break;
+        }
+      }
+      if (nG == 1)
+        return dnas::fail(DNAS_E_NOMEM, "a read of " + std::to_string(Lmax) + " bases needs " + std::to_string(perRead(C) * 8) +
+                                            " bytes of lattice segments and checkpoints; the lattice arena has " + std::to_string(m->arenaCap));
+      nG = (nG + 1) / 2;
+    }
+    SegmentGroup g{g0, nG, C, Lmax / C + 1, (H + (size_t)C + 1) * colDoubles + 8, (size_t)(Lmax / C + 1) * (H + 1) * colDoubles, cp->tabEntries};
+    cp->groupPeak = std::max(cp->groupPeak, (size_t)nG * (g.workStride + g.ckStride));
+    cp->tabEntries += (size_t)g.nSeg * (size_t)nG;
+    cp->groupLaunches += 2 * (size_t)g.nSeg;
+    cp->groups.push_back(g);
+    g0 += nG;
+  }
+
+  // ---- the other reads, in whole-lattice batches
+  cp->slotOff.assign((size_t)n_reads, 0);
+  cp->batchStart.assign(1, nSeg);
+  size_t used = 0;
+  for (int64_t i = 0; i < nSeg; ++i) cp->columns += lenOf(i) + 1;
+  // one work-group per read: equal batches rather than full ones and a remainder (a launch costs whole rounds of
+  // work-groups).  Persistent work-groups that pull reads from a queue: full batches (a multiple of the work-groups)
+  // and a remainder, which then only costs the rounds it needs.
+  const int64_t nPlain = n_reads - nSeg;
+  const int64_t nFull = std::max<int64_t>(1, (nPlain + m->maxSlots - 1) / m->maxSlots);
+  const int64_t perBatch = (m->tier == 1 && m->persistentGroups > 0) ? m->maxSlots : (nPlain + nFull - 1) / nFull;
+  for (int64_t i = nSeg; i < n_reads; ++i) {
+    const uint64_t L = (uint64_t)lenOf(i);
+    const size_t need = colDoubles * (size_t)(L + 1) + 8;   // + a spare cell (tier A, local mode: S(N-1, L) before its overwrite)
+    if (need > arenaCapDoubles)
+      return dnas::fail(DNAS_E_NOMEM, "a single read's lattice (" + std::to_string(need * 8) +
+                                          " bytes) exceeds the lattice arena (" + std::to_string(m->arenaCap) + ") and checkpoint=never");
+    if (i - cp->batchStart.back() >= perBatch || used + need > arenaCapDoubles) {
+      cp->batchStart.push_back(i);
+      used = 0;
+    }
+    cp->slotOff[(size_t)i] = used;
+    used += need;
+    cp->peak = std::max(cp->peak, used);
+    cp->columns += (int64_t)L + 1;
+  }
+  if (nPlain > 0) cp->batchStart.push_back(n_reads);
+  return DNAS_OK;
+}
+
+// the kernels index their substitution tables with the base codes: anything but 0..3 must not reach them
+int check_device_bases(dnas_model* m, const uint8_t* d_bases, size_t nBases) {
+  if (!nBases) return DNAS_OK;
+  HIP_TRY(hipMemsetAsync(m->dRounds + 8, 0, sizeof(unsigned long long), m->stream));
+  hipLaunchKernelGGL(check_bases_kernel, dim3((unsigned)std::min<size_t>((nBases + 255) / 256, 4096)), dim3(256), 0, m->stream,
+                     d_bases, nBases, m->dRounds + 8);
+  HIP_TRY(hipGetLastError());
+  unsigned long long bad = 0;
+  HIP_TRY(hipMemcpyAsync(&bad, m->dRounds + 8, sizeof bad, hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  if (bad) return dnas::fail(DNAS_E_BAD_BASE, "base code > 3 in the device buffer (bases are 0..3 = ACGT)");
+  return DNAS_OK;
+}
+
+// One fill launch over nB reads (their indices at batchRead, their lattices at arena + slots[.]) on the model's fill stream;
+// colRange: the columns to fill per read (segments), or null for whole reads.
+struct FillLauncher {
+  dnas_model* m;
+  const uint8_t* d_bases;
+  double* d_out_loglike;
+  size_t syncAt = 0, launches = 0;
+
+  int operator()(const int32_t* batchRead, const uint64_t* slots, int nB, const int* colRange) {
+    ++launches;
+    RoctxRange fillRange(m->tier == 2 ? "viterbi fill (tier C)" : (m->tier == 1 ? "viterbi fill (tier A)" : "viterbi fill (tier B)"));
+    if (m->tier == 0) {
+      const int maskWords = (m->dm.N + 31) / 32 + 1;
+      hipLaunchKernelGGL(viterbi_fill_kernel, dim3(nB), dim3(kFillThreads), 2 * (size_t)maskWords * sizeof(unsigned), m->stream, m->dm, d_bases,
+                         (const uint64_t*)m->dReadOff, batchRead, slots, m->arena, d_out_loglike, m->dRounds, maskWords, colRange);
+      HIP_TRY(hipGetLastError());
+      return DNAS_OK;
+    }
+    TierALaunch la{m->argsA, m->dEntTab, m->dMetaTab, d_bases, m->dReadOff, batchRead, slots,
+                   m->arena, d_out_loglike, m->dRounds, nullptr, nullptr, nullptr, 0, nB, 0ull, colRange, m->dFwdTab};
+    unsigned grid = (unsigned)nB;
+    if (m->tier == 1 && m->persistentGroups > 0 && nB > m->persistentGroups && !colRange) {
+      grid = (unsigned)m->persistentGroups;      // the work-groups pull the reads beyond the first `grid` from a queue
+      HIP_TRY(hipMemsetAsync(m->dRounds + 9, 0, sizeof(unsigned long long), m->stream));
+    }
+    int nClusters = 0;
+    if (m->tier == 2) {
+      // a cluster of G work-groups per read, persistent over the reads of the launch.  Blocks b and b + 8 share
+      // an XCD (observed dispatch order; the kernel is correct under any placement): the members of a cluster are
+      // 8 blocks apart, cluster = (b / 8 / G) * 8 + b % 8.
+      const int G = m->plan.G;
+      nClusters = std::min(nB, m->maxClusters);
+      la.xbuf = m->dXbuf; la.syncWords = m->dSync; la.foldTab = m->dFoldTab; la.nClusters = nClusters; la.timeoutTicks = m->timeoutTicks;
+      grid = (unsigned)(8 * G * ((nClusters + 7) / 8));
+      const size_t nX = m->xStride * (size_t)nClusters;
+      hipLaunchKernelGGL(fill_neginf_kernel, dim3((unsigned)((nX + 255) / 256)), dim3(256), 0, m->stream, m->dXbuf, nX);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemsetAsync(m->dSync, 0, (size_t)nClusters * 64 * sizeof(unsigned), m->stream));
+    }
+    size_t laSize = sizeof la;
+    void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &la, HIP_LAUNCH_PARAM_BUFFER_SIZE, &laSize, HIP_LAUNCH_PARAM_END};
+    HIP_TRY(hipModuleLaunchKernel(colRange ? m->fillSeg : m->fillA, grid, 1, 1, (unsigned)m->plan.T, 1, 1, (unsigned)m->plan.ldsBytes,
+                                  m->stream, nullptr, config));
+    if (m->tier == 2) {
+      // the watchdog words of this launch: [1] of every sync block (checked in dnas_model_sync)
+      HIP_TRY(hipMemcpyAsync(m->syncCheck.data() + syncAt * (size_t)m->maxClusters * 64, m->dSync,
+                             (size_t)nClusters * 64 * sizeof(unsigned), hipMemcpyDeviceToHost, m->stream));
+      ++syncAt;
+    }
+    return DNAS_OK;
+  }
+};
+
+// the register/LDS kernel built with -DDNAS_SEGMENTS=1, compiled when a call first needs it
+int ensure_segment_kernel(dnas_model* m) {
+  if (m->tier == 0 || m->fillSeg) return DNAS_OK;
+  try {
+    const std::vector<char> code = dnas::jitCompile(m->jitDefs + "\n-DDNAS_SEGMENTS=1", m->plan.key + "+segments");
+    if (hipModuleLoadData(&m->moduleSeg, code.data()) != hipSuccess ||
+        hipModuleGetFunction(&m->fillSeg, m->moduleSeg, "viterbi_fill_tiera") != hipSuccess)
+      throw std::runtime_error("hipModuleLoadData/GetFunction failed");
+  } catch (const std::exception& e) {
+    m->fillSeg = nullptr;
+    return dnas::fail(DNAS_E_DEVICE, std::string("bounded-memory decode: the segment kernel is unavailable: ") + e.what());
+  }
+  return DNAS_OK;
+}
+
+// The groups of the bounded-memory decode, everything in order on the fill stream.  events: 4 per group (pass 1, pass 2).
+int run_segment_groups(dnas_model* m, const CallPlan& cp, const uint64_t* read_offsets, FillLauncher& fill, const uint8_t* d_bases,
+                       char* d_out_sym, uint32_t* d_out_len, uint8_t* d_out_status) {
+  const DevModel& d = m->dm;
+  const size_t colDoubles = (size_t)d.storedLanes * (size_t)d.Npad, H = (size_t)d.D + 1;
+  auto lenOf = [&](int64_t i) { return (int64_t)(read_offsets[cp.order[(size_t)i] + 1] - read_offsets[cp.order[(size_t)i]]); };
+  // per group and segment: the column range and the (virtual) lattice origin of every read
+  std::vector<int> ranges(2 * cp.tabEntries);
+  std::vector<uint64_t> segSlot(cp.tabEntries);
+  for (const SegmentGroup& g : cp.groups)
+    for (int64_t sg = 0; sg < g.nSeg; ++sg)
+      for (int64_t j = 0; j < g.n; ++j) {
+        const size_t at = g.tabAt + (size_t)sg * (size_t)g.n + (size_t)j;
+        const int64_t L = lenOf(g.first + j), c0 = sg * g.C;
+        ranges[2 * at] = (int)c0;
+        ranges[2 * at + 1] = (int)std::min(L, c0 + g.C - 1);
+        // column c of the segment sits at work(j) + (c - c0 + H) columns: the origin the kernels add c * column to
+        segSlot[at] = (uint64_t)((size_t)j * g.workStride + H * colDoubles) - (uint64_t)((size_t)c0 * colDoubles);
+      }
+  if (m->dColRange) { (void)hipFree(m->dColRange); (void)hipFree(m->dSegSlot); (void)hipFree(m->dWalks); }
+  m->dColRange = nullptr; m->dSegSlot = nullptr; m->dWalks = nullptr;
+  HIP_TRY(hipMalloc((void**)&m->dColRange, ranges.size() * sizeof(int)));
+  HIP_TRY(hipMalloc((void**)&m->dSegSlot, segSlot.size() * sizeof(uint64_t)));
+  HIP_TRY(hipMalloc((void**)&m->dWalks, (size_t)cp.nSegmented * sizeof(TracebackWalk)));
+  HIP_TRY(hipMemcpy(m->dColRange, ranges.data(), ranges.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(m->dSegSlot, segSlot.data(), segSlot.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(m->dWalks, 0, (size_t)cp.nSegmented * sizeof(TracebackWalk)));
+  const size_t headDoubles = (H + 1) * colDoubles;
+  for (size_t gi = 0; gi < cp.groups.size(); ++gi) {
+    const SegmentGroup& g = cp.groups[gi];
+    RoctxRange groupRange("viterbi bounded-memory group");
+    double* const work = m->arena;
+    double* const ckpt = m->arena + (size_t)g.n * g.workStride;
+    // reads of the group that reach segment sg (sorted longest first: a prefix)
+    auto reach = [&](int64_t sg) {
+      int64_t k = 0;
+      while (k < g.n && lenOf(g.first + k) >= sg * g.C) ++k;
+      return (int)k;
+    };
+    auto copyRows = [&](double* dst, size_t dstStride, const double* src, size_t srcStride, int rows) -> int {
+      hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)std::min<size_t>((headDoubles + 255) / 256, 256), (unsigned)rows), dim3(256), 0,
+                         m->stream, dst, src, dstStride, srcStride, headDoubles);
+      HIP_TRY(hipGetLastError());
+      return DNAS_OK;
+    };
+    int rc;
+    HIP_TRY(hipEventRecord(m->events[4 * gi], m->stream));
+    for (int64_t sg = 0; sg < g.nSeg; ++sg) {            // pass 1
+      const int nAct = reach(sg);
+      if (nAct == 0) break;
+      if (sg > 0) {
+        // the last H columns of the segment before and the hand-over lane behind them: kept, and moved to the front
+        if ((rc = copyRows(ckpt + (size_t)sg * headDoubles, g.ckStride, work + (size_t)g.C * colDoubles, g.workStride, nAct)) != DNAS_OK) return rc;
+        if ((rc = copyRows(work, g.workStride, ckpt + (size_t)sg * headDoubles, g.ckStride, nAct)) != DNAS_OK) return rc;
+      }
+      const size_t at = g.tabAt + (size_t)sg * (size_t)g.n;
+      if ((rc = fill(m->dBatchRead + g.first, m->dSegSlot + at, nAct, m->dColRange + 2 * at)) != DNAS_OK) return rc;
+    }
+    HIP_TRY(hipEventRecord(m->events[4 * gi + 1], m->stream));
+    HIP_TRY(hipEventRecord(m->events[4 * gi + 2], m->stream));
+    for (int64_t sg = g.nSeg - 1; sg >= 0; --sg) {        // pass 2
+      const int nAct = reach(sg), nAgain = sg + 1 < g.nSeg ? reach(sg + 1) : 0;
+      if (nAct == 0) continue;
+      const size_t at = g.tabAt + (size_t)sg * (size_t)g.n;
+      if (nAgain > 0) {
+        if (sg > 0 && (rc = copyRows(work, g.workStride, ckpt + (size_t)sg * headDoubles, g.ckStride, nAgain)) != DNAS_OK) return rc;
+        if ((rc = fill(m->dBatchRead + g.first, m->dSegSlot + at, nAgain, m->dColRange + 2 * at)) != DNAS_OK) return rc;
+      }
+      hipLaunchKernelGGL(viterbi_traceback_wave_kernel, dim3((nAct + 3) / 4), dim3(256), 0, m->stream, d, d_bases,
+                         (const uint64_t*)m->dReadOff, (const int32_t*)(m->dBatchRead + g.first), (const uint64_t*)(m->dSegSlot + at),
+                         (const double*)m->arena, d_out_sym, (const uint64_t*)m->dOutOff, d_out_len, d_out_status, nAct, m->dEvents,
+                         (const uint64_t*)m->dEvOff, m->dEvLen, (const int*)(m->dColRange + 2 * at), m->dWalks + g.first);
+      HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(m->events[4 * gi + 3], m->stream));
+  }
+  return DNAS_OK;
+}
+
+}  // namespace
+
 extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const uint64_t* read_offsets,
                                          const uint8_t* d_bases, char* d_out_sym, const uint64_t* out_offsets,
                                          uint32_t* d_out_len, double* d_out_loglike, uint8_t* d_out_status) {
@@ -467,118 +742,19 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
   m->stats = dnas_batch_stats{};
   m->statsPending = false;
   if (n_reads == 0) return DNAS_OK;
-  {
-    // the kernels index their substitution tables with the base codes: anything but 0..3 must not reach them
-    const size_t nBases = (size_t)(read_offsets[n_reads] - read_offsets[0]);
-    if (nBases) {
-      HIP_TRY(hipMemsetAsync(m->dRounds + 8, 0, sizeof(unsigned long long), m->stream));
-      hipLaunchKernelGGL(check_bases_kernel, dim3((unsigned)std::min<size_t>((nBases + 255) / 256, 4096)), dim3(256), 0, m->stream,
-                         d_bases + read_offsets[0], nBases, m->dRounds + 8);
-      HIP_TRY(hipGetLastError());
-      unsigned long long bad = 0;
-      HIP_TRY(hipMemcpyAsync(&bad, m->dRounds + 8, sizeof bad, hipMemcpyDeviceToHost, m->stream));
-      HIP_TRY(hipStreamSynchronize(m->stream));
-      if (bad) return dnas::fail(DNAS_E_BAD_BASE, "base code > 3 in the device buffer (bases are 0..3 = ACGT)");
-    }
-  }
+  int rc = check_device_bases(m, d_bases + read_offsets[0], (size_t)(read_offsets[n_reads] - read_offsets[0]));
+  if (rc != DNAS_OK) return rc;
   const DevModel& d = m->dm;
-  const size_t lanes = (size_t)d.D + 2;
-  const size_t colDoubles = (size_t)d.storedLanes * (size_t)d.Npad;
 
-  // longest reads first: a batch's work-groups then finish together
-  std::vector<int32_t> order((size_t)n_reads);
-  std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
-    return read_offsets[a + 1] - read_offsets[a] > read_offsets[b + 1] - read_offsets[b];
-  });
-  // two arena halves: batch i fills half (i & 1) while the traceback of batch i-1 still reads the other
-  const size_t arenaCapDoubles = m->arenaCap / sizeof(double) / 2;
-  auto lenOf = [&](int64_t i) { return (int64_t)(read_offsets[order[(size_t)i] + 1] - read_offsets[order[(size_t)i]]); };
-  for (int64_t i = 0; i < n_reads; ++i)
-    if (lenOf(i) > 0x7ffffff0ll) return dnas::fail(DNAS_E_UNSUPPORTED, "read too long");
-
-  // ---- bounded-memory decode (the reference holds every read's whole lattice, viterbi.h:48-50): the reads whose lattice does
-  // not fit half the arena -- the longest, first in sorted order -- are decoded in groups, in segments of C columns:
-  //   pass 1  fill segment after segment into a work buffer of H + C + 1 columns per read, keeping of every segment only its
-  //           last H columns and the hand-over lane (what the fill of the next segment and a traceback step look back at)
-  //   pass 2  from the last segment to the first: restore the checkpoint in front of the segment, fill it again (the last one
-  //           is still there), and let the traceback walk it; a walk that leaves the segment is parked until the next launch
-  // Fill work doubles; memory per read drops from L + 1 columns to about 2 sqrt((L + 1)(H + 1)).
-  struct CkGroup { int64_t first, n, C, nSeg; size_t workStride, ckStride, tabAt; };
-  std::vector<CkGroup> groups;
-  const size_t H = (size_t)d.D + 1;
-  int64_t nCk = 0;
-  if (m->checkpointMode == 1) nCk = n_reads;
-  else if (m->checkpointMode == 0)
-    while (nCk < n_reads && colDoubles * (size_t)(lenOf(nCk) + 1) + 8 > arenaCapDoubles) ++nCk;
-  size_t ckPeak = 0, ckTab = 0, ckLaunches = 0;
-  {
-    const size_t budget = m->arenaCap / sizeof(double);
-    const int64_t groupMax = m->tier == 2 ? m->maxClusters : m->maxSlots;
-    for (int64_t g0 = 0; g0 < nCk;) {
-      const int64_t Lmax = lenOf(g0);
-      int64_t nG = std::min(nCk - g0, groupMax), C = 0;
-      auto perRead = [&](int64_t c) {
-        return (H + (size_t)c + 1) * colDoubles + 8 + (size_t)(Lmax / c + 1) * (H + 1) * colDoubles;
-      };
-      const int64_t cMin = (int64_t)H + 1;
-      for (;;) {
-        const size_t per = budget / (size_t)nG;
-        if (m->segmentCols > 0) {
-          C = std::max<int64_t>(cMin, m->segmentCols);
-          if (perRead(C) <= per) break;
-        } else {
-          C = std::max<int64_t>(cMin, (int64_t)std::ceil(std::sqrt((double)(Lmax + 1) * (double)(H + 1))));
-          if (perRead(C) <= per) {
-            while (C < Lmax + 1 && perRead(std::min(2 * C, Lmax + 1)) <= per) C = std::min(2 * C, Lmax + 1);
-            break;
-          }
-        }
-        if (nG == 1)
-          return dnas::fail(DNAS_E_NOMEM, "a read of " + std::to_string(Lmax) + " bases needs " + std::to_string(perRead(C) * 8) +
-                                              " bytes of lattice segments and checkpoints; the lattice arena has " + std::to_string(m->arenaCap));
-        nG = (nG + 1) / 2;
-      }
-      CkGroup g{g0, nG, C, Lmax / C + 1, (H + (size_t)C + 1) * colDoubles + 8, (size_t)(Lmax / C + 1) * (H + 1) * colDoubles, ckTab};
-      ckPeak = std::max(ckPeak, (size_t)nG * (g.workStride + g.ckStride));
-      ckTab += (size_t)g.nSeg * (size_t)nG;
-      ckLaunches += 2 * (size_t)g.nSeg;
-      groups.push_back(g);
-      g0 += nG;
-    }
-  }
-  m->lastCheckpointed = nCk;
-
-  std::vector<uint64_t> slotOff((size_t)n_reads);
-  std::vector<int64_t> batchStart{nCk};
-  size_t used = 0, peak = 0;
-  int64_t columns = 0;
-  for (int64_t i = 0; i < nCk; ++i) columns += lenOf(i) + 1;
-  // one work-group per read: equal batches rather than full ones and a remainder (a launch costs whole rounds of
-  // work-groups).  Persistent work-groups that pull reads from a queue: full batches (a multiple of the work-groups)
-  // and a remainder, which then only costs the rounds it needs.
-  const int64_t nPlain = n_reads - nCk;
-  const int64_t nFull = std::max<int64_t>(1, (nPlain + m->maxSlots - 1) / m->maxSlots);
-  const int64_t perBatch = (m->tier == 1 && m->persistentGroups > 0) ? m->maxSlots : (nPlain + nFull - 1) / nFull;
-  for (int64_t i = nCk; i < n_reads; ++i) {
-    const uint64_t L = (uint64_t)lenOf(i);
-    const size_t need = colDoubles * (size_t)(L + 1) + 8;   // + a spare cell (tier A, local mode: S(N-1, L) before its overwrite)
-    if (need > arenaCapDoubles)
-      return dnas::fail(DNAS_E_NOMEM, "a single read's lattice (" + std::to_string(need * 8) +
-                                          " bytes) exceeds the lattice arena (" + std::to_string(m->arenaCap) + ") and checkpoint=never");
-    if (i - batchStart.back() >= perBatch || used + need > arenaCapDoubles) {
-      batchStart.push_back(i);
-      used = 0;
-    }
-    slotOff[(size_t)i] = used;
-    used += need;
-    peak = std::max(peak, used);
-    columns += (int64_t)L + 1;
-  }
-  if (nPlain > 0) batchStart.push_back(n_reads);
+  CallPlan cp;
+  if ((rc = plan_call(m, n_reads, read_offsets, &cp)) != DNAS_OK) return rc;
+  std::vector<uint64_t>& slotOff = cp.slotOff;
+  const std::vector<int64_t>& batchStart = cp.batchStart;
+  const size_t nBatches = batchStart.size() - 1, nGroups = cp.groups.size();
+  m->lastCheckpointed = cp.nSegmented;
   m->lastBatchStart = batchStart;
-  const bool pingPong = batchStart.size() > 2;          // more than one batch
-  const size_t arenaNeed = std::max((pingPong ? 2 : 1) * peak, ckPeak) * sizeof(double);
+  const bool pingPong = nBatches > 1;
+  const size_t arenaNeed = std::max((pingPong ? 2 : 1) * cp.peak, cp.groupPeak) * sizeof(double);
   if (arenaNeed > m->arenaBytes) {
     if (m->arena) HIP_TRY(hipFree(m->arena));
     m->arena = nullptr;
@@ -586,7 +762,7 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
     HIP_TRY(hipMalloc((void**)&m->arena, arenaNeed));
     m->arenaBytes = arenaNeed;
   }
-  m->halfDoubles = peak;
+  m->halfDoubles = cp.peak;
   if ((size_t)n_reads + 1 > m->schedCap) {
     if (m->dBatchRead) { (void)hipFree(m->dBatchRead); (void)hipFree(m->dSlotOff); (void)hipFree(m->dReadOff); (void)hipFree(m->dOutOff); }
     m->dBatchRead = nullptr; m->dSlotOff = m->dReadOff = m->dOutOff = nullptr;
@@ -598,12 +774,16 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
     HIP_TRY(hipMalloc((void**)&m->dOutOff, cap * sizeof(uint64_t)));
     m->schedCap = cap;
   }
+  // slot offsets of odd batches point into the second half
+  if (pingPong)
+    for (size_t b = 1; b < nBatches; b += 2)
+      for (int64_t i = batchStart[b]; i < batchStart[b + 1]; ++i) slotOff[(size_t)i] += m->halfDoubles;
   m->lastSlotOff = slotOff;
-  m->lastBatchRead = order;
+  m->lastBatchRead = cp.order;
   m->lastReadOff.assign(read_offsets, read_offsets + n_reads + 1);
   m->lastBases = d_bases;
   // host vectors stay alive until the copies complete (synchronous copies keep this simple)
-  HIP_TRY(hipMemcpy(m->dBatchRead, order.data(), (size_t)n_reads * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(m->dBatchRead, cp.order.data(), (size_t)n_reads * sizeof(int32_t), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(m->dSlotOff, slotOff.data(), (size_t)n_reads * sizeof(uint64_t), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(m->dReadOff, read_offsets, ((size_t)n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(m->dOutOff, out_offsets, ((size_t)n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
@@ -620,7 +800,6 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
     HIP_TRY(hipMemcpy(m->dEvOff, m->evOff.data(), ((size_t)n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(m->dEvLen, 0, (size_t)n_reads * sizeof(uint32_t)));
   }
-  const size_t nBatches = batchStart.size() - 1, nGroups = groups.size();
   const size_t nTimed = nBatches + nGroups;              // 4 timing events each: the groups first, then the batches
   while (m->events.size() < 4 * nTimed) {
     hipEvent_t e;
@@ -633,147 +812,14 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
     m->sync.push_back(e);
   }
   if (m->tier == 2) {
-    m->syncCheck.assign((nBatches + ckLaunches) * (size_t)m->maxClusters * 64, 0u);
-    m->syncLaunches = nBatches + ckLaunches;
-  }
-  const int maskWords = (d.N + 31) / 32 + 1;
-  const size_t ldsBytes = 2 * (size_t)maskWords * sizeof(unsigned);
-  // slot offsets of odd batches point into the second half
-  if (pingPong) {
-    for (size_t b = 1; b < nBatches; b += 2)
-      for (int64_t i = batchStart[b]; i < batchStart[b + 1]; ++i) slotOff[(size_t)i] += m->halfDoubles;
-    m->lastSlotOff = slotOff;
-    HIP_TRY(hipMemcpy(m->dSlotOff, slotOff.data(), (size_t)n_reads * sizeof(uint64_t), hipMemcpyHostToDevice));
+    m->syncCheck.assign((nBatches + cp.groupLaunches) * (size_t)m->maxClusters * 64, 0u);
+    m->syncLaunches = nBatches + cp.groupLaunches;
   }
 
-  // one fill launch over nB reads (their indices at batchRead, their lattices at arena + slots[.]), on m->stream
-  size_t syncAt = 0, fillLaunches = 0;
-  auto launchFill = [&](const int32_t* batchRead, const uint64_t* slots, int nB, const int* colRange) -> int {
-    ++fillLaunches;
-    RoctxRange fillRange(m->tier == 2 ? "viterbi fill (tier C)" : (m->tier == 1 ? "viterbi fill (tier A)" : "viterbi fill (tier B)"));
-    if (m->tier >= 1) {
-      TierALaunch la{m->argsA, m->dEntTab, m->dMetaTab, d_bases, m->dReadOff, batchRead, slots,
-                     m->arena, d_out_loglike, m->dRounds, nullptr, nullptr, nullptr, 0, nB, 0ull, colRange, m->dFwdTab};
-      unsigned grid = (unsigned)nB;
-      if (m->tier == 1 && m->persistentGroups > 0 && nB > m->persistentGroups && !colRange) {
-        grid = (unsigned)m->persistentGroups;      // the work-groups pull the reads beyond the first `grid` from a queue
-        HIP_TRY(hipMemsetAsync(m->dRounds + 9, 0, sizeof(unsigned long long), m->stream));
-      }
-      int nClusters = 0;
-      if (m->tier == 2) {
-        // a cluster of G work-groups per read, persistent over the reads of the launch.  Blocks b and b + 8 share
-        // an XCD (observed dispatch order; the kernel is correct under any placement): the members of a cluster are
-        // 8 blocks apart, cluster = (b / 8 / G) * 8 + b % 8.
-        const int G = m->plan.G;
-        nClusters = std::min(nB, m->maxClusters);
-        la.xbuf = m->dXbuf; la.syncWords = m->dSync; la.foldTab = m->dFoldTab; la.nClusters = nClusters; la.timeoutTicks = m->timeoutTicks;
-        grid = (unsigned)(8 * G * ((nClusters + 7) / 8));
-        const size_t nX = m->xStride * (size_t)nClusters;
-        hipLaunchKernelGGL(fill_neginf_kernel, dim3((unsigned)((nX + 255) / 256)), dim3(256), 0, m->stream, m->dXbuf, nX);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemsetAsync(m->dSync, 0, (size_t)nClusters * 64 * sizeof(unsigned), m->stream));
-      }
-      size_t laSize = sizeof la;
-      void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &la, HIP_LAUNCH_PARAM_BUFFER_SIZE, &laSize, HIP_LAUNCH_PARAM_END};
-      HIP_TRY(hipModuleLaunchKernel(colRange ? m->fillSeg : m->fillA, grid, 1, 1, (unsigned)m->plan.T, 1, 1, (unsigned)m->plan.ldsBytes,
-                                    m->stream, nullptr, config));
-      if (m->tier == 2) {
-        // the watchdog words of this launch: [1] of every sync block (checked in dnas_model_sync)
-        HIP_TRY(hipMemcpyAsync(m->syncCheck.data() + syncAt * (size_t)m->maxClusters * 64, m->dSync,
-                               (size_t)nClusters * 64 * sizeof(unsigned), hipMemcpyDeviceToHost, m->stream));
-        ++syncAt;
-      }
-    } else {
-      hipLaunchKernelGGL(viterbi_fill_kernel, dim3(nB), dim3(kFillThreads), ldsBytes, m->stream, d, d_bases,
-                         (const uint64_t*)m->dReadOff, batchRead, slots, m->arena, d_out_loglike, m->dRounds, maskWords, colRange);
-      HIP_TRY(hipGetLastError());
-    }
-    return DNAS_OK;
-  };
-
-  // ---- the groups of the bounded-memory decode, everything in order on m->stream
-  if (nGroups && m->tier >= 1 && !m->fillSeg) {
-    try {
-      const std::vector<char> code = dnas::jitCompile(m->jitDefs + "\n-DDNAS_SEGMENTS=1", m->plan.key + "+segments");
-      if (hipModuleLoadData(&m->moduleSeg, code.data()) != hipSuccess ||
-          hipModuleGetFunction(&m->fillSeg, m->moduleSeg, "viterbi_fill_tiera") != hipSuccess)
-        throw std::runtime_error("hipModuleLoadData/GetFunction failed");
-    } catch (const std::exception& e) {
-      m->fillSeg = nullptr;
-      return dnas::fail(DNAS_E_DEVICE, std::string("bounded-memory decode: the segment kernel is unavailable: ") + e.what());
-    }
-  }
+  FillLauncher fill{m, d_bases, d_out_loglike};
   if (nGroups) {
-    // per group and segment: the column range and the (virtual) lattice origin of every read
-    std::vector<int> ranges(2 * ckTab);
-    std::vector<uint64_t> segSlot(ckTab);
-    for (const CkGroup& g : groups)
-      for (int64_t sg = 0; sg < g.nSeg; ++sg)
-        for (int64_t j = 0; j < g.n; ++j) {
-          const size_t at = g.tabAt + (size_t)sg * (size_t)g.n + (size_t)j;
-          const int64_t L = lenOf(g.first + j), c0 = sg * g.C;
-          ranges[2 * at] = (int)c0;
-          ranges[2 * at + 1] = (int)std::min(L, c0 + g.C - 1);
-          // column c of the segment sits at work(j) + (c - c0 + H) columns: the origin the kernels add c * column to
-          segSlot[at] = (uint64_t)((size_t)j * g.workStride + H * colDoubles) - (uint64_t)((size_t)c0 * colDoubles);
-        }
-    if (m->dColRange) { (void)hipFree(m->dColRange); (void)hipFree(m->dSegSlot); (void)hipFree(m->dWalks); }
-    m->dColRange = nullptr; m->dSegSlot = nullptr; m->dWalks = nullptr;
-    HIP_TRY(hipMalloc((void**)&m->dColRange, ranges.size() * sizeof(int)));
-    HIP_TRY(hipMalloc((void**)&m->dSegSlot, segSlot.size() * sizeof(uint64_t)));
-    HIP_TRY(hipMalloc((void**)&m->dWalks, (size_t)nCk * sizeof(TracebackWalk)));
-    HIP_TRY(hipMemcpy(m->dColRange, ranges.data(), ranges.size() * sizeof(int), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(m->dSegSlot, segSlot.data(), segSlot.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(m->dWalks, 0, (size_t)nCk * sizeof(TracebackWalk)));
-    const size_t headDoubles = (H + 1) * colDoubles;
-    for (size_t gi = 0; gi < nGroups; ++gi) {
-      const CkGroup& g = groups[gi];
-      RoctxRange groupRange("viterbi bounded-memory group");
-      double* const work = m->arena;
-      double* const ckpt = m->arena + (size_t)g.n * g.workStride;
-      // reads of the group that reach segment sg (sorted longest first: a prefix)
-      auto reach = [&](int64_t sg) {
-        int64_t k = 0;
-        while (k < g.n && lenOf(g.first + k) >= sg * g.C) ++k;
-        return (int)k;
-      };
-      auto copyRows = [&](double* dst, size_t dstStride, const double* src, size_t srcStride, int rows) -> int {
-        hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)std::min<size_t>((headDoubles + 255) / 256, 256), (unsigned)rows), dim3(256), 0,
-                           m->stream, dst, src, dstStride, srcStride, headDoubles);
-        HIP_TRY(hipGetLastError());
-        return DNAS_OK;
-      };
-      int rcl;
-      HIP_TRY(hipEventRecord(m->events[4 * gi], m->stream));
-      for (int64_t sg = 0; sg < g.nSeg; ++sg) {            // pass 1
-        const int nAct = reach(sg);
-        if (nAct == 0) break;
-        if (sg > 0) {
-          // the last H columns of the segment before and the hand-over lane behind them: kept, and moved to the front
-          if ((rcl = copyRows(ckpt + (size_t)sg * headDoubles, g.ckStride, work + (size_t)g.C * colDoubles, g.workStride, nAct)) != DNAS_OK) return rcl;
-          if ((rcl = copyRows(work, g.workStride, ckpt + (size_t)sg * headDoubles, g.ckStride, nAct)) != DNAS_OK) return rcl;
-        }
-        const size_t at = g.tabAt + (size_t)sg * (size_t)g.n;
-        if ((rcl = launchFill(m->dBatchRead + g.first, m->dSegSlot + at, nAct, m->dColRange + 2 * at)) != DNAS_OK) return rcl;
-      }
-      HIP_TRY(hipEventRecord(m->events[4 * gi + 1], m->stream));
-      HIP_TRY(hipEventRecord(m->events[4 * gi + 2], m->stream));
-      for (int64_t sg = g.nSeg - 1; sg >= 0; --sg) {        // pass 2
-        const int nAct = reach(sg), nAgain = sg + 1 < g.nSeg ? reach(sg + 1) : 0;
-        if (nAct == 0) continue;
-        const size_t at = g.tabAt + (size_t)sg * (size_t)g.n;
-        if (nAgain > 0) {
-          if (sg > 0 && (rcl = copyRows(work, g.workStride, ckpt + (size_t)sg * headDoubles, g.ckStride, nAgain)) != DNAS_OK) return rcl;
-          if ((rcl = launchFill(m->dBatchRead + g.first, m->dSegSlot + at, nAgain, m->dColRange + 2 * at)) != DNAS_OK) return rcl;
-        }
-        hipLaunchKernelGGL(viterbi_traceback_wave_kernel, dim3((nAct + 3) / 4), dim3(256), 0, m->stream, d, d_bases,
-                           (const uint64_t*)m->dReadOff, (const int32_t*)(m->dBatchRead + g.first), (const uint64_t*)(m->dSegSlot + at),
-                           (const double*)m->arena, d_out_sym, (const uint64_t*)m->dOutOff, d_out_len, d_out_status, nAct, m->dEvents,
-                           (const uint64_t*)m->dEvOff, m->dEvLen, (const int*)(m->dColRange + 2 * at), m->dWalks + g.first);
-        HIP_TRY(hipGetLastError());
-      }
-      HIP_TRY(hipEventRecord(m->events[4 * gi + 3], m->stream));
-    }
+    if ((rc = ensure_segment_kernel(m)) != DNAS_OK) return rc;
+    if ((rc = run_segment_groups(m, cp, read_offsets, fill, d_bases, d_out_sym, d_out_len, d_out_status)) != DNAS_OK) return rc;
   }
 
   for (size_t b = 0; b < nBatches; ++b) {
@@ -783,7 +829,7 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
     // the half this batch fills was last read by the traceback of batch b-2
     if (b >= 2) HIP_TRY(hipStreamWaitEvent(m->stream, m->sync[2 * (b - 2) + 1], 0));
     HIP_TRY(hipEventRecord(m->events[ev], m->stream));
-    { const int rcl = launchFill(m->dBatchRead + s, m->dSlotOff + s, nB, nullptr); if (rcl != DNAS_OK) return rcl; }
+    if ((rc = fill(m->dBatchRead + s, m->dSlotOff + s, nB, nullptr)) != DNAS_OK) return rc;
     HIP_TRY(hipEventRecord(m->events[ev + 1], m->stream));
     HIP_TRY(hipEventRecord(m->sync[2 * b], m->stream));
     RoctxRange tbRange("viterbi traceback");
@@ -798,10 +844,10 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
                          (const double*)m->arena, d_out_sym, (const uint64_t*)m->dOutOff, d_out_len, d_out_status, nB, m->dEvents,
                          (const uint64_t*)m->dEvOff, m->dEvLen, (const int*)nullptr, (TracebackWalk*)nullptr);
     else
-    hipLaunchKernelGGL(viterbi_traceback_kernel, dim3((nB + kTraceThreads - 1) / kTraceThreads), dim3(kTraceThreads), 0,
-                       m->stream2, d, d_bases, (const uint64_t*)m->dReadOff, (const int32_t*)(m->dBatchRead + s),
-                       (const uint64_t*)(m->dSlotOff + s), (const double*)m->arena, d_out_sym,
-                       (const uint64_t*)m->dOutOff, d_out_len, d_out_status, nB, m->dEvents, (const uint64_t*)m->dEvOff, m->dEvLen);
+      hipLaunchKernelGGL(viterbi_traceback_kernel, dim3((nB + kTraceThreads - 1) / kTraceThreads), dim3(kTraceThreads), 0,
+                         m->stream2, d, d_bases, (const uint64_t*)m->dReadOff, (const int32_t*)(m->dBatchRead + s),
+                         (const uint64_t*)(m->dSlotOff + s), (const double*)m->arena, d_out_sym,
+                         (const uint64_t*)m->dOutOff, d_out_len, d_out_status, nB, m->dEvents, (const uint64_t*)m->dEvOff, m->dEvLen);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(m->events[ev + 3], m->stream2));
     HIP_TRY(hipEventRecord(m->sync[2 * b + 1], m->stream2));
@@ -811,10 +857,10 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
     (void)hipEventDestroy(m->events.back());
     m->events.pop_back();
   }
-  m->stats.fill_launches = (int64_t)fillLaunches;
-  m->stats.checkpointed_reads = nCk;
-  m->stats.columns = columns;
-  m->stats.lattice_bytes = (int64_t)(8 * lanes * (size_t)d.N) * columns;
+  m->stats.fill_launches = (int64_t)fill.launches;
+  m->stats.checkpointed_reads = cp.nSegmented;
+  m->stats.columns = cp.columns;
+  m->stats.lattice_bytes = (int64_t)(8 * ((size_t)d.D + 2) * (size_t)d.N) * cp.columns;
   m->statsPending = true;
   return DNAS_OK;
 }
