@@ -746,22 +746,33 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
   if (rc != DNAS_OK) return rc;
   const DevModel& d = m->dm;
 
+  // plan the call against the arena cap; if the device cannot give that much any more (the cap was taken from the free memory
+  // when the model was created -- another process may have come since), plan once more against what is free now: smaller
+  // batches, or segments for the reads that no longer fit
   CallPlan cp;
-  if ((rc = plan_call(m, n_reads, read_offsets, &cp)) != DNAS_OK) return rc;
+  for (int attempt = 0;; ++attempt) {
+    cp = CallPlan();
+    if ((rc = plan_call(m, n_reads, read_offsets, &cp)) != DNAS_OK) return rc;
+    const size_t need = std::max((cp.batchStart.size() > 2 ? 2 : 1) * cp.peak, cp.groupPeak) * sizeof(double);
+    if (need <= m->arenaBytes) break;
+    if (m->arena) HIP_TRY(hipFree(m->arena));
+    m->arena = nullptr;
+    m->arenaBytes = 0;
+    const hipError_t e = hipMalloc((void**)&m->arena, need);
+    if (e == hipSuccess) { m->arenaBytes = need; break; }
+    (void)hipGetLastError();
+    m->arena = nullptr;
+    size_t freeB = 0, totalB = 0;
+    if (attempt > 0 || e != hipErrorOutOfMemory || hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB / 10 * 8 >= m->arenaCap)
+      return dnas::fail(DNAS_E_DEVICE, "hipMalloc of the lattice arena (" + std::to_string(need) + " bytes): " + hipGetErrorString(e));
+    m->arenaCap = freeB / 10 * 8;
+  }
   std::vector<uint64_t>& slotOff = cp.slotOff;
   const std::vector<int64_t>& batchStart = cp.batchStart;
   const size_t nBatches = batchStart.size() - 1, nGroups = cp.groups.size();
   m->lastCheckpointed = cp.nSegmented;
   m->lastBatchStart = batchStart;
   const bool pingPong = nBatches > 1;
-  const size_t arenaNeed = std::max((pingPong ? 2 : 1) * cp.peak, cp.groupPeak) * sizeof(double);
-  if (arenaNeed > m->arenaBytes) {
-    if (m->arena) HIP_TRY(hipFree(m->arena));
-    m->arena = nullptr;
-    m->arenaBytes = 0;
-    HIP_TRY(hipMalloc((void**)&m->arena, arenaNeed));
-    m->arenaBytes = arenaNeed;
-  }
   m->halfDoubles = cp.peak;
   if ((size_t)n_reads + 1 > m->schedCap) {
     if (m->dBatchRead) { (void)hipFree(m->dBatchRead); (void)hipFree(m->dSlotOff); (void)hipFree(m->dReadOff); (void)hipFree(m->dOutOff); }

@@ -264,3 +264,33 @@ def test_both_traceback_kernels_agree(da, ref_data):
         out_b, ll_b, st_b = b.decode(reads)
         assert out_a == out_b and np.array_equal(ll_a.view(np.uint64), ll_b.view(np.uint64)) and list(st_a) == list(st_b)
         a.close(); b.close()
+
+
+def test_arena_replanned_when_the_device_has_less_memory_than_at_creation(da, ref_data):
+    """The arena cap is taken from the free memory when the model is created.  If the device cannot give that much any more
+    (here: a tensor takes all but 20 GB afterwards), the call is planned again against what is free -- more, smaller batches --
+    and returns the same results."""
+    import torch
+    m = da.Machine.fromFile(os.path.join(ref_data, "s16h74l4c4.json"))
+    params = da.MutatorParams.fromFlags(global_=True)
+    import random
+    reads = []
+    for i in range(300):                                        # one batch of 34 GB of lattice
+        rng = random.Random(4000 + i)
+        reads.append(m.encodeBytes(bytes(rng.randrange(256) for _ in range(29))))
+    ref_dec = da.ViterbiDecoder(m, params)
+    want = ref_dec.decode(reads)
+    assert ref_dec.stats()["fill_launches"] == 1
+    ref_dec.close()
+    dec = da.ViterbiDecoder(m, params)
+    free, _ = torch.cuda.mem_get_info()
+    hog = torch.empty(free - (20 << 30), dtype=torch.uint8, device="cuda")
+    try:
+        got = dec.decode(reads)
+        st = dec.stats()
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+    assert st["fill_launches"] > 1 and st["checkpointed_reads"] == 0
+    assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+    dec.close()
