@@ -54,7 +54,7 @@ std::vector<int> partitionStates(int N, const std::vector<Edge>& edges, const st
   return part;
 }
 
-TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T) {
+TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const int forwardedRows = -1) {
   TierAPlan p;
   const int N = fm.n_states, D = fm.max_dup_len;
   if (T != 1024 && T != 512) { TierAPlan bad; bad.whyNot = "work-groups of 512 or 1024 threads"; return bad; }
@@ -127,7 +127,7 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T) {
     }
   }
 
-  // ---- forwarded runs (experimental: DNAS_PLAN_FWD=1, one work-group per read only).  A state whose ONLY in-edge comes
+  // ---- forwarded runs (one work-group per read only; forwardedRows / DNAS_PLAN_FWD).  A state whose ONLY in-edge comes
   // from the state in the row right above it, in the same thread, needs no LDS accumulator, no read and no idle check: its
   // cells are a function of that thread's registers ("F rows" of the program; the kernel evaluates them from S and D of
   // the row above).  Candidates: the first such child of every state along the depth-first walk, in runs of at most maxRun
@@ -135,11 +135,15 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T) {
   // program long enough).  Measured on s16h74l4c4 (7 of 14 rows become F rows, 5 700 states sit under their parent): bit
   // exact, but 0.44 of the roofline against 0.53 -- the heads are left with 7 rows to run down (18.7 sweeps per column
   // instead of 14.4) and a sweep costs the same (3.5 k cycles against 3.3 k): it is bound by the rows that grow, not by the
-  // LDS round trips of the rows that do not.  Off unless asked for.
+  // LDS round trips of the rows that do not.  On water64.1*l4c4 (long unbranched runs) the same program is 6.6 % faster.
+  // Which one a machine gets is therefore measured, not guessed: the runtime times both on a synthetic read when a
+  // model is first created for the machine (runtime.hip, option autotune).
   int maxRun = 3;
   if (const char* e = getenv("DNAS_PLAN_RUN")) maxRun = std::max(1, std::min(4, atoi(e)));
-  bool useFwd = false;
-  if (const char* e = getenv("DNAS_PLAN_FWD")) useFwd = G == 1 && atoi(e) != 0;
+  bool useFwd = forwardedRows > 0;
+  if (forwardedRows < 0)
+    if (const char* e = getenv("DNAS_PLAN_FWD")) useFwd = atoi(e) != 0;
+  useFwd = useFwd && G == 1;
   if (!useFwd) maxRun = 1;
   std::vector<int> candChild(N, -1), candParent(N, -1), candEdge(N, -1), runDepth(N, 0);
   if (maxRun > 1)
@@ -857,7 +861,7 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T) {
 
 }  // namespace
 
-TierAPlan buildTierAPlan(const dnas_flat_model& fm, int threads) { return buildPlan(fm, 1, threads); }
+TierAPlan buildTierAPlan(const dnas_flat_model& fm, int threads, int forwardedRows) { return buildPlan(fm, 1, threads, forwardedRows); }
 
 TierAPlan buildClusterPlan(const dnas_flat_model& fm, int G, int threads) {
   if (G < 2) { TierAPlan p; p.whyNot = "a cluster has at least two members"; return p; }

@@ -74,7 +74,9 @@ constexpr size_t kTierALdsLimit = 160 * 1024 - 1024;  // leave room for the stat
 
 // One work-group per read; fails (ok = false) when the machine does not fit one CU.
 // threads: 1024 (16 waves of 128 registers) or 512 (8 waves of 256 registers, twice the rows per thread).
-TierAPlan buildTierAPlan(const dnas_flat_model& fm, int threads = kTierAThreads);
+// forwardedRows: 1 a row program with F rows (states evaluated from the registers of the row above), 0 without,
+// -1 as the environment says (DNAS_PLAN_FWD, default without).
+TierAPlan buildTierAPlan(const dnas_flat_model& fm, int threads = kTierAThreads, int forwardedRows = -1);
 // G work-groups per read (G >= 2); fails when the states do not fit G CUs or no common row program exists.
 TierAPlan buildClusterPlan(const dnas_flat_model& fm, int G, int threads = kTierAThreads);
 // The smallest cluster that fits (tries G = gMin .. kTierCMaxMembers).

@@ -59,6 +59,24 @@ std::string kernelCacheDir() {
 #define DNAS_ARCH "gfx950"
 #endif
 
+unsigned long long cacheHash(const std::string& text) { return (unsigned long long)fnv1a(tieraSource(), fnv1a(text + "|" DNAS_ARCH)); }
+
+std::string cacheNoteRead(const std::string& name) {
+  std::ifstream in(kernelCacheDir() + "/" + name);
+  if (!in) return "";
+  return std::string((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+}
+
+void cacheNoteWrite(const std::string& name, const std::string& text) {
+  const std::string dir = kernelCacheDir(), path = dir + "/" + name, tmp = path + "." + std::to_string((long)getpid()) + ".tmp";
+  mkdir(dir.c_str(), 0755);
+  std::ofstream out(tmp);
+  if (!out) return;
+  out << text;
+  out.close();
+  if (rename(tmp.c_str(), path.c_str()) != 0) remove(tmp.c_str());
+}
+
 std::vector<char> jitCompile(const std::string& defines, const std::string& key) {
   const std::string src = tieraSource();
   int rtcMajor = 0, rtcMinor = 0;

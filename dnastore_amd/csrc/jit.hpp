@@ -16,5 +16,9 @@ std::string libraryDir();
 // hiprtc version is reused.  The cache directory is <library dir>/kcache, or $DNAS_KCACHE_DIR.
 std::vector<char> jitCompile(const std::string& defines, const std::string& key);
 std::string kernelCacheDir();
+// A small text record next to the cached code objects (plan autotuning decisions): "" when absent; writes are best effort.
+std::string cacheNoteRead(const std::string& name);
+void cacheNoteWrite(const std::string& name, const std::string& text);
+unsigned long long cacheHash(const std::string& text);
 
 }  // namespace dnas

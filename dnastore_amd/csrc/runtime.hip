@@ -198,6 +198,67 @@ int collect_stats(dnas_model* m) {
 
 }  // namespace
 
+namespace {
+
+// With or without F rows (host/plan.cpp)?  The answer depends on the machine -- 17 % slower on s16h74l4c4, 7 % faster on
+// water64.1*l4c4 -- and the plan's cost model does not predict it, so it is measured: when a model is first created for a
+// machine, both row programs are built, compiled and timed on a synthetic read (one work-group each), and the verdict is
+// kept next to the cached code objects (kcache/tune_<hash>.txt; the hash covers both plans and the kernel source).
+int tune_forwarded_rows(const dnas_flat_model* fm, int device_id, int threads, int* choice) {
+  *choice = 0;
+  // the machine's graph (not the error model: the row programs do not depend on it) names the record
+  std::string graph((const char*)&fm->n_states, sizeof fm->n_states);
+  auto add = [&](const void* ptr, size_t bytes) { graph.append((const char*)ptr, bytes); };
+  add(&fm->max_dup_len, sizeof fm->max_dup_len); add(&threads, sizeof threads);
+  add(fm->ein_ptr, ((size_t)fm->n_states + 1) * sizeof(int32_t)); add(fm->ein_src, (size_t)fm->n_emit * sizeof(int32_t));
+  add(fm->ein_score, (size_t)fm->n_emit * sizeof(double)); add(fm->ein_base, (size_t)fm->n_emit);
+  add(fm->nin_ptr, ((size_t)fm->n_states + 1) * sizeof(int32_t)); add(fm->nin_src, (size_t)fm->n_null * sizeof(int32_t));
+  add(fm->nin_score, (size_t)fm->n_null * sizeof(double));
+  char name[64];
+  snprintf(name, sizeof name, "tune_%016llx.txt", dnas::cacheHash(graph));
+  const std::string note = dnas::cacheNoteRead(name);
+  if (!note.empty()) { *choice = note[0] == '1'; return DNAS_OK; }
+  const dnas::TierAPlan plain = dnas::buildTierAPlan(*fm, threads, 0), fwd = dnas::buildTierAPlan(*fm, threads, 1);
+  if (!plain.ok || !fwd.ok || fwd.nFwdRows == 0) {
+    if (plain.ok) dnas::cacheNoteWrite(name, "0  (no row program with forwarded rows for this machine)\n");
+    return DNAS_OK;
+  }
+  // four copies of a pseudo-random read of 160 bases: four work-groups, a few milliseconds per program
+  const int L = 160, nReads = 4;
+  std::vector<uint8_t> bases((size_t)L * nReads);
+  unsigned long long x = 88172645463325252ull;
+  for (int i = 0; i < L; ++i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; bases[(size_t)i] = (uint8_t)(x & 3); }
+  for (int r = 1; r < nReads; ++r) std::copy(bases.begin(), bases.begin() + L, bases.begin() + (size_t)r * L);
+  std::vector<uint64_t> readOff(nReads + 1), outOff(nReads + 1);
+  const size_t cap = 4 * (size_t)L + 64;
+  for (int r = 0; r <= nReads; ++r) { readOff[(size_t)r] = (uint64_t)r * L; outOff[(size_t)r] = (uint64_t)r * cap; }
+  std::vector<char> sym(cap * nReads);
+  std::vector<uint32_t> len(nReads);
+  std::vector<double> ll(nReads);
+  std::vector<uint8_t> st(nReads);
+  double ms[2] = {0, 0};
+  for (int v = 0; v < 2; ++v) {
+    dnas_model* t = nullptr;
+    const std::string options = "tier=A,autotune=0,plan_fwd=" + std::to_string(v) + ",threads=" + std::to_string(threads);
+    int rc = dnas_model_create_ex(fm, device_id, (size_t)1 << 30, options.c_str(), &t);
+    if (rc != DNAS_OK) return DNAS_OK;          // (whatever is wrong will be reported by the creation that asked for this)
+    for (int rep = 0; rep < 2 && rc == DNAS_OK; ++rep)
+      rc = dnas_viterbi_batch(t, nReads, readOff.data(), bases.data(), sym.data(), outOff.data(), len.data(), ll.data(), st.data());
+    dnas_batch_stats s{};
+    if (rc == DNAS_OK) rc = dnas_model_last_stats(t, &s);
+    dnas_model_destroy(t);
+    if (rc != DNAS_OK) return DNAS_OK;
+    ms[v] = s.fill_ms;
+  }
+  *choice = ms[1] > 0 && ms[1] < 0.97 * ms[0] ? 1 : 0;
+  char text[256];
+  snprintf(text, sizeof text, "%d  plain rows %.3f ms, forwarded rows %.3f ms (fill of %d synthetic reads of %d bases)\n", *choice, ms[0], ms[1], nReads, L);
+  dnas::cacheNoteWrite(name, text);
+  return DNAS_OK;
+}
+
+}  // namespace
+
 extern "C" int dnas_has_device_code(void) { return 1; }
 
 extern "C" int dnas_device_count(void) {
@@ -211,7 +272,8 @@ extern "C" int dnas_model_create(const dnas_flat_model* fm, int device_id, size_
 }
 
 // options: "key=value,key=value"; keys tier (A|B|C), cluster (work-groups per read), threads (512 | 1024 per work-group),
-// max_clusters, max_slots, cluster_timeout_s, persistent, traceback, arena_fraction, checkpoint, segment.  A key that is absent falls back to the environment variable DNAS_<KEY>.
+// max_clusters, max_slots, cluster_timeout_s, persistent, traceback, arena_fraction, checkpoint, segment, plan_fwd (row program
+// with F rows: 0 | 1), autotune (0: do not time the two row programs when plan_fwd is not given).  A key that is absent falls back to the environment variable DNAS_<KEY>.
 extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, size_t arena_bytes, const char* options,
                                     dnas_model** out) {
   if (!fm || !out) return dnas::fail(DNAS_E_INVALID, "dnas_model_create: null argument");
@@ -282,15 +344,24 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
     const char* forceOpt = opt("tier");
     const std::string force = forceOpt ? forceOpt : "";
     const char want = !force.empty() ? (char)(force[0] & ~0x20) : 0;
-    int wantG = 0, wantT = 0;
+    int wantG = 0, wantT = 0, wantFwd = -1;
+    bool autotune = true;
     if (const char* s = opt("cluster")) wantG = atoi(s);
     if (const char* s = opt("threads")) wantT = atoi(s);
+    if (const char* s = opt("plan_fwd")) wantFwd = atoi(s) != 0;
+    if (const char* s = opt("autotune")) autotune = atoi(s) != 0;
     if (want == 'B') {
       m->tierNote = "tier B forced by DNAS_TIER";
     } else {
       std::string whyNotA;
       if (want != 'C' && wantG < 2) {
-        m->plan = dnas::buildTierAPlan(*fm, wantT ? wantT : dnas::kTierAThreads);
+        const int threadsA = wantT ? wantT : dnas::kTierAThreads;
+        if (wantFwd < 0 && autotune) {
+          int rcTune = tune_forwarded_rows(fm, device_id, threadsA, &wantFwd);
+          if (rcTune != DNAS_OK) return bail(rcTune);
+          if (hipSetDevice(device_id) != hipSuccess) return bail(dnas::fail(DNAS_E_DEVICE, "hipSetDevice failed"));
+        }
+        m->plan = dnas::buildTierAPlan(*fm, threadsA, wantFwd < 0 ? 0 : wantFwd);
         if (!m->plan.ok) whyNotA = m->plan.whyNot;
       } else {
         m->plan.ok = false;

@@ -294,3 +294,29 @@ def test_arena_replanned_when_the_device_has_less_memory_than_at_creation(da, re
     assert st["fill_launches"] > 1 and st["checkpointed_reads"] == 0
     assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
     dec.close()
+
+
+def test_row_program_autotune(da, ref_data, tmp_path, monkeypatch):
+    """autotune=1 (the library's default; the suite runs with DNAS_AUTOTUNE=0): the first model of a machine times the row
+    program with and without F rows on a synthetic read, keeps the verdict in the kernel cache, and later models read it.
+    Whatever it picks, the results are the plain program's, bit for bit."""
+    monkeypatch.setenv("DNAS_KCACHE_DIR", str(tmp_path))
+    monkeypatch.setenv("DNAS_AUTOTUNE", "1")
+    water = da.Machine.compose(da.Machine.fromFile(os.path.join(ref_data, "water64.1.json")), da.Machine.fromFile(os.path.join(ref_data, "l4c4.json")))
+    params = da.MutatorParams.fromFlags(global_=True)
+    import random
+    rng = random.Random(3)
+    reads = [water.encodeBytes(bytes(rng.randrange(256) for _ in range(8))) for _ in range(5)]
+    tuned = da.ViterbiDecoder(water, params)
+    notes = [f for f in os.listdir(tmp_path) if f.startswith("tune_")]
+    assert len(notes) == 1
+    verdict = open(os.path.join(tmp_path, notes[0])).read()
+    assert verdict[0] in "01" and "forwarded rows" in verdict
+    got = tuned.decode(reads)
+    again = da.ViterbiDecoder(water, params)                       # reads the record: no second one appears
+    assert [f for f in os.listdir(tmp_path) if f.startswith("tune_")] == notes and again.tier == tuned.tier
+    plain = da.ViterbiDecoder(water, params, options="plan_fwd=0")
+    want = plain.decode(reads)
+    assert got[0] == want[0] and np.array_equal(got[1].view(np.uint64), want[1].view(np.uint64)) and np.array_equal(got[2], want[2])
+    for d in (tuned, again, plain):
+        d.close()
