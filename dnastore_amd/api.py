@@ -183,13 +183,13 @@ class FlatModel:
                                           member_of.ctypes.data, lds.ctypes.data, lat.ctypes.data, fold.ctypes.data))
         out = dict(G=G, K=K, T=T, n_entries=ne, n_s_rows=int(info[4]), n_inbox_rows=int(info[5]), shapes=shapes, entries=ent, meta=meta,
                    member_of=member_of, lds_index=lds, lattice_slot=lat, fold=fold[:, :int(info[5])])
-        if G == 1:     # the F rows of the tier-A plan: fwd_rows int32[K][3], fwd_tab uint32[words][T] (include/dnastore_amd.h)
-            nw = ctypes.c_int32()
-            _l.check(_l.lib().dnas_tiera_plan_forwarded(self.view, None, None, 0, ctypes.addressof(nw)))
-            fwd_rows = np.zeros((K, 3), dtype=np.int32)
-            fwd_tab = np.zeros((max(nw.value, 1), T), dtype=np.uint32)
-            _l.check(_l.lib().dnas_tiera_plan_forwarded(self.view, fwd_rows.ctypes.data, fwd_tab.ctypes.data, fwd_tab.size, ctypes.addressof(nw)))
-            out["fwd_rows"], out["fwd_tab"] = fwd_rows, fwd_tab[:nw.value]
+        # the F rows of the plan: fwd_rows int32[K][3], fwd_tab uint32[G][words][T] (include/dnastore_amd.h)
+        nw = ctypes.c_int32()
+        _l.check(_l.lib().dnas_tiera_plan_forwarded(self.view, G, None, None, 0, ctypes.addressof(nw)))
+        fwd_rows = np.zeros((K, 3), dtype=np.int32)
+        fwd_tab = np.zeros((G, max(nw.value, 1), T), dtype=np.uint32)
+        _l.check(_l.lib().dnas_tiera_plan_forwarded(self.view, G, fwd_rows.ctypes.data, fwd_tab.ctypes.data, fwd_tab.size, ctypes.addressof(nw)))
+        out["fwd_rows"], out["fwd_tab"] = fwd_rows, fwd_tab[:, :nw.value]
         return out
 
     def precompile_cluster(self, members=0):

@@ -127,36 +127,6 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const i
     }
   }
 
-  // ---- forwarded runs (one work-group per read only; forwardedRows / DNAS_PLAN_FWD).  A state whose ONLY in-edge comes
-  // from the state in the row right above it, in the same thread, needs no LDS accumulator, no read and no idle check: its
-  // cells are a function of that thread's registers ("F rows" of the program; the kernel evaluates them from S and D of
-  // the row above).  Candidates: the first such child of every state along the depth-first walk, in runs of at most maxRun
-  // states; the dealing below decides which of them really end up under their parent (a run needs a segment of the
-  // program long enough).  Measured on s16h74l4c4 (7 of 14 rows become F rows, 5 700 states sit under their parent): bit
-  // exact, but 0.44 of the roofline against 0.53 -- the heads are left with 7 rows to run down (18.7 sweeps per column
-  // instead of 14.4) and a sweep costs the same (3.5 k cycles against 3.3 k): it is bound by the rows that grow, not by the
-  // LDS round trips of the rows that do not.  On water64.1*l4c4 (long unbranched runs) the same program is 6.6 % faster.
-  // Which one a machine gets is therefore measured, not guessed: the runtime times both on a synthetic read when a
-  // model is first created for the machine (runtime.hip, option autotune).
-  int maxRun = 3;
-  if (const char* e = getenv("DNAS_PLAN_RUN")) maxRun = std::max(1, std::min(4, atoi(e)));
-  bool useFwd = forwardedRows > 0;
-  if (forwardedRows < 0)
-    if (const char* e = getenv("DNAS_PLAN_FWD")) useFwd = atoi(e) != 0;
-  useFwd = useFwd && G == 1;
-  if (!useFwd) maxRun = 1;
-  std::vector<int> candChild(N, -1), candParent(N, -1), candEdge(N, -1), runDepth(N, 0);
-  if (maxRun > 1)
-    for (int u : walk) {
-      if (runDepth[u] + 1 >= maxRun) continue;
-      for (int e : outOf[u]) {
-        const int c = edges[e].dst;
-        if (c == u || c == 0 || inOf[c].size() != 1 || parent[c] != u || candParent[c] >= 0) continue;
-        candChild[u] = c; candParent[c] = u; candEdge[c] = e; runDepth[c] = runDepth[u] + 1;
-        break;
-      }
-    }
-
   // ---- which member of the cluster owns which state.  A state with an in-edge from another member gets a slot in
   // its member's INBOX: cells of the cluster's exchange buffer that the other members offer into and that the
   // member folds into the state's LDS accumulators, slot r*T + t by thread t.
@@ -179,6 +149,36 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const i
   p.crossEdges = edges.empty() ? 0. : (double)nCross / (double)edges.size();
   for (int j = 0; j < N; ++j)
     if (parent[j] >= 0 && part[parent[j]] != part[j]) parent[j] = -1;   // the dealing follows a member's own subtrees
+  // ---- forwarded runs (forwardedRows / DNAS_PLAN_FWD; in a cluster: inside a member).  A state whose ONLY in-edge comes
+  // from the state in the row right above it, in the same thread, needs no LDS accumulator, no read and no idle check: its
+  // cells are a function of that thread's registers ("F rows" of the program; the kernel evaluates them from S and D of
+  // the row above).  Candidates: the first such child of every state along the depth-first walk, in runs of at most maxRun
+  // states; the dealing below decides which of them really end up under their parent (a run needs a segment of the
+  // program long enough).  Measured on s16h74l4c4 (7 of 14 rows become F rows, 5 700 states sit under their parent): bit
+  // exact, but 0.44 of the roofline against 0.53 -- the heads are left with 7 rows to run down (18.7 sweeps per column
+  // instead of 14.4) and a sweep costs the same (3.5 k cycles against 3.3 k): it is bound by the rows that grow, not by the
+  // LDS round trips of the rows that do not.  On water64.1*l4c4 (long unbranched runs) the same program is 6.6 % faster.
+  // Which one a machine gets is therefore measured, not guessed: the runtime times both on a synthetic read when a
+  // model is first created for the machine (runtime.hip, option autotune).
+  int maxRun = 3;
+  if (const char* e = getenv("DNAS_PLAN_RUN")) maxRun = std::max(1, std::min(4, atoi(e)));
+  bool useFwd = forwardedRows > 0;
+  if (forwardedRows < 0)
+    if (const char* e = getenv("DNAS_PLAN_FWD")) useFwd = atoi(e) != 0;
+  if (useFwd) pairSweep = false;          // (the pair sweep reads accumulators that F rows do not have)
+  if (!useFwd) maxRun = 1;
+  std::vector<int> candChild(N, -1), candParent(N, -1), candEdge(N, -1), runDepth(N, 0);
+  if (maxRun > 1)
+    for (int u : walk) {
+      if (runDepth[u] + 1 >= maxRun) continue;
+      for (int e : outOf[u]) {
+        const int c = edges[e].dst;
+        if (c == u || c == 0 || inOf[c].size() != 1 || parent[c] != u || candParent[c] >= 0) continue;
+        candChild[u] = c; candParent[c] = u; candEdge[c] = e; runDepth[c] = runDepth[u] + 1;
+        break;
+      }
+    }
+
   std::vector<std::vector<int>> walkOf(G);
   for (int j : walk) walkOf[part[j]].push_back(j);
   int nInboxRows = 0;
@@ -524,15 +524,19 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const i
     const int minS = (nNullDestMax + T - 1) / T;
     // ---- with F rows: the segment structure from the census of candidate runs
     if (maxRun > 1) {
+      // (of the member with the most runs of each length: the members share the program)
       std::vector<long> nRun(maxRun + 1, 0);
-      long nNullHeads = 0;
-      for (int j = 0; j < N; ++j)
-        if (candParent[j] < 0) {
-          int L = 1;
-          for (int c = candChild[j]; c >= 0; c = candChild[c]) ++L;
-          ++nRun[L];
-          nNullHeads += type[j][1];
-        }
+      {
+        std::vector<std::vector<long>> per(G, std::vector<long>(maxRun + 1, 0));
+        for (int j = 0; j < N; ++j)
+          if (candParent[j] < 0) {
+            int L = 1;
+            for (int c = candChild[j]; c >= 0; c = candChild[c]) ++L;
+            ++per[part[j]][L];
+          }
+        for (int g = 0; g < G; ++g)
+          for (int L = 1; L <= maxRun; ++L) nRun[L] = std::max(nRun[L], per[g][L]);
+      }
       // segments of L rows, L = maxRun .. 2, then lone rows: runs that find no segment of their length are cut
       long bestFwd = -1;
       std::vector<int> bestSegs;
@@ -567,6 +571,7 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const i
           for (int c = 0; c < bestSegs[L]; ++c) { segLen[k] = L; k += L; }
         long nUnder = 0;
         for (int j = 0; j < N; ++j) nUnder += candParent[j] >= 0 && type[j][1];
+        nUnder /= G;
         // states with null in-edges that end up under their parent need no S cell: fewer S rows may do
         const int minSF = std::max(0, (int)((nNullDestMax - std::min(nUnder, bestFwd) * 7 / 10 + T - 1) / T));
         if (getenv("DNAS_PLAN_DEBUG")) {
@@ -576,7 +581,6 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const i
           for (int L = maxRun; L >= 1; --L) fprintf(stderr, " %dx%d", bestSegs[L], L);
           fprintf(stderr, "; up to %ld states under their parent; S rows from %d\n", bestFwd, minSF);
         }
-        (void)nNullHeads;
         tryPrograms(segLen, minSF);
       }
     }
@@ -807,14 +811,14 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const i
   // F rows: per lane, the edge from the state above -- bit 0 valid, bit 1 null edge, [2:4) score class, [4:6) emitted base;
   // five rows to a 32-bit word (word (f-1)/5, bits 6*((f-1)%5) ...), f = the row's index among the F rows
   p.nFwdWords = (p.nFwdRows + 4) / 5;
-  p.fwdTab.assign((size_t)std::max(p.nFwdWords, 1) * T, 0u);
+  p.fwdTab.assign((size_t)G * std::max(p.nFwdWords, 1) * T, 0u);
   for (int j = 0; j < N; ++j)
     if (attOf[j] >= 0) {
       const int row = rowOfState[j], f = p.rows[row].fwd - 1;
       if (f < 0 || rowOfState[attOf[j]] != row - 1 || laneOf[attOf[j]] != laneOf[j]) return no("internal: a forwarded state is not under its parent");
       const Edge& e = edges[candEdge[j]];
       const unsigned bits = 1u | (e.isNull ? 2u : 0u) | ((unsigned)e.sc << 2) | ((unsigned)(e.base & 3) << 4);
-      p.fwdTab[(size_t)(f / 5) * T + laneOf[j]] |= bits << (6 * (f % 5));
+      p.fwdTab[((size_t)part[j] * std::max(p.nFwdWords, 1) + (size_t)(f / 5)) * T + laneOf[j]] |= bits << (6 * (f % 5));
     }
 
   // fold table: inbox slot r*T + t of a member -> LDS cells of the state behind it: DC byte address >> 3 | SC byte
@@ -863,16 +867,16 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const i
 
 TierAPlan buildTierAPlan(const dnas_flat_model& fm, int threads, int forwardedRows) { return buildPlan(fm, 1, threads, forwardedRows); }
 
-TierAPlan buildClusterPlan(const dnas_flat_model& fm, int G, int threads) {
+TierAPlan buildClusterPlan(const dnas_flat_model& fm, int G, int threads, int forwardedRows) {
   if (G < 2) { TierAPlan p; p.whyNot = "a cluster has at least two members"; return p; }
-  return buildPlan(fm, G, threads);
+  return buildPlan(fm, G, threads, forwardedRows);
 }
 
-TierAPlan buildSmallestClusterPlan(const dnas_flat_model& fm, int gMin, int threads) {
+TierAPlan buildSmallestClusterPlan(const dnas_flat_model& fm, int gMin, int threads, int forwardedRows) {
   TierAPlan last;
   const int lo = std::max(2, std::max(gMin, (int)(((long)fm.n_states * 100 / 93 + (long)kTierAMaxRows * kTierAThreads - 1) / ((long)kTierAMaxRows * kTierAThreads))));
   for (int G = lo; G <= kTierCMaxMembers; ++G) {
-    last = buildPlan(fm, G, threads);
+    last = buildPlan(fm, G, threads, forwardedRows);
     if (last.ok) return last;
   }
   if (last.whyNot.empty()) last.whyNot = "more than " + std::to_string(kTierCMaxMembers) + " work-groups per read";
@@ -882,8 +886,8 @@ TierAPlan buildSmallestClusterPlan(const dnas_flat_model& fm, int gMin, int thre
 // Tier C as the runtime asks for it: members = 0 -> the smallest cluster; threads = 0 -> work-groups of 512 threads
 // (8 waves of 256 registers, twice the rows per thread: no register spills, and the machine fits fewer CUs) when that
 // needs no more work-groups per read than 1024-thread ones (measured faster at equal size), else 1024.
-TierAPlan chooseClusterPlan(const dnas_flat_model& fm, int members, int threads) {
-  auto build = [&](int t) { return members >= 2 ? buildClusterPlan(fm, members, t) : buildSmallestClusterPlan(fm, 2, t); };
+TierAPlan chooseClusterPlan(const dnas_flat_model& fm, int members, int threads, int forwardedRows) {
+  auto build = [&](int t) { return members >= 2 ? buildClusterPlan(fm, members, t, forwardedRows) : buildSmallestClusterPlan(fm, 2, t, forwardedRows); };
   if (threads == 512 || threads == 1024) return build(threads);
   TierAPlan narrow = build(512);
   // both shapes hold the same number of states per work-group: when the narrow one already gets by with the fewest

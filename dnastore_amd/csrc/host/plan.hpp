@@ -56,7 +56,7 @@ struct TierAPlan {
   std::vector<uint32_t> metaTab;  // [G][K][T]  mdl | ctx<<4 | flags
   std::vector<uint32_t> foldTab;  // [G][nGRows][T]  inbox slot -> LDS cells of its state (DC addr >> 3 | SC addr >> 3 << 16), 0: unused
   int nFwdRows = 0, nFwdWords = 0;
-  std::vector<uint32_t> fwdTab;   // [nFwdWords][T]  F rows: the edge from the state above, 6 bits per row (plan.cpp)
+  std::vector<uint32_t> fwdTab;   // [G][nFwdWords][T]  F rows: the edge from the state above, 6 bits per row (plan.cpp)
   double score[4] = {0, 0, 0, 0};
   size_t ldsBytes = 0;
   double fillRatio = 0;           // real entries / padded entries
@@ -78,10 +78,10 @@ constexpr size_t kTierALdsLimit = 160 * 1024 - 1024;  // leave room for the stat
 // -1 as the environment says (DNAS_PLAN_FWD, default without).
 TierAPlan buildTierAPlan(const dnas_flat_model& fm, int threads = kTierAThreads, int forwardedRows = -1);
 // G work-groups per read (G >= 2); fails when the states do not fit G CUs or no common row program exists.
-TierAPlan buildClusterPlan(const dnas_flat_model& fm, int G, int threads = kTierAThreads);
+TierAPlan buildClusterPlan(const dnas_flat_model& fm, int G, int threads = kTierAThreads, int forwardedRows = -1);
 // The smallest cluster that fits (tries G = gMin .. kTierCMaxMembers).
-TierAPlan buildSmallestClusterPlan(const dnas_flat_model& fm, int gMin = 2, int threads = kTierAThreads);
+TierAPlan buildSmallestClusterPlan(const dnas_flat_model& fm, int gMin = 2, int threads = kTierAThreads, int forwardedRows = -1);
 // What the runtime uses for tier C: members = 0 -> smallest cluster, threads = 0 -> 512 when that needs fewer members.
-TierAPlan chooseClusterPlan(const dnas_flat_model& fm, int members, int threads);
+TierAPlan chooseClusterPlan(const dnas_flat_model& fm, int members, int threads, int forwardedRows = -1);
 
 }  // namespace dnas

@@ -204,12 +204,13 @@ namespace {
 // water64.1*l4c4 -- and the plan's cost model does not predict it, so it is measured: when a model is first created for a
 // machine, both row programs are built, compiled and timed on a synthetic read (one work-group each), and the verdict is
 // kept next to the cached code objects (kcache/tune_<hash>.txt; the hash covers both plans and the kernel source).
-int tune_forwarded_rows(const dnas_flat_model* fm, int device_id, int threads, int* choice) {
+int tune_forwarded_rows(const dnas_flat_model* fm, int device_id, int members, int threads, int* choice) {
+  // members: 1 tier A; 0 / >= 2 tier C (the smallest cluster / that many work-groups per read)
   *choice = 0;
   // the machine's graph (not the error model: the row programs do not depend on it) names the record
   std::string graph((const char*)&fm->n_states, sizeof fm->n_states);
   auto add = [&](const void* ptr, size_t bytes) { graph.append((const char*)ptr, bytes); };
-  add(&fm->max_dup_len, sizeof fm->max_dup_len); add(&threads, sizeof threads);
+  add(&fm->max_dup_len, sizeof fm->max_dup_len); add(&threads, sizeof threads); add(&members, sizeof members);
   add(fm->ein_ptr, ((size_t)fm->n_states + 1) * sizeof(int32_t)); add(fm->ein_src, (size_t)fm->n_emit * sizeof(int32_t));
   add(fm->ein_score, (size_t)fm->n_emit * sizeof(double)); add(fm->ein_base, (size_t)fm->n_emit);
   add(fm->nin_ptr, ((size_t)fm->n_states + 1) * sizeof(int32_t)); add(fm->nin_src, (size_t)fm->n_null * sizeof(int32_t));
@@ -218,8 +219,9 @@ int tune_forwarded_rows(const dnas_flat_model* fm, int device_id, int threads, i
   snprintf(name, sizeof name, "tune_%016llx.txt", dnas::cacheHash(graph));
   const std::string note = dnas::cacheNoteRead(name);
   if (!note.empty()) { *choice = note[0] == '1'; return DNAS_OK; }
-  const dnas::TierAPlan plain = dnas::buildTierAPlan(*fm, threads, 0), fwd = dnas::buildTierAPlan(*fm, threads, 1);
-  if (!plain.ok || !fwd.ok || fwd.nFwdRows == 0) {
+  const dnas::TierAPlan plain = members == 1 ? dnas::buildTierAPlan(*fm, threads, 0) : dnas::chooseClusterPlan(*fm, members, threads, 0);
+  const dnas::TierAPlan fwd = members == 1 ? dnas::buildTierAPlan(*fm, threads, 1) : dnas::chooseClusterPlan(*fm, members, threads, 1);
+  if (!plain.ok || !fwd.ok || fwd.nFwdRows == 0 || fwd.G != plain.G) {
     if (plain.ok) dnas::cacheNoteWrite(name, "0  (no row program with forwarded rows for this machine)\n");
     return DNAS_OK;
   }
@@ -239,7 +241,8 @@ int tune_forwarded_rows(const dnas_flat_model* fm, int device_id, int threads, i
   double ms[2] = {0, 0};
   for (int v = 0; v < 2; ++v) {
     dnas_model* t = nullptr;
-    const std::string options = "tier=A,autotune=0,plan_fwd=" + std::to_string(v) + ",threads=" + std::to_string(threads);
+    const std::string options = (members == 1 ? std::string("tier=A") : "tier=C,cluster=" + std::to_string(plain.G)) + ",autotune=0,plan_fwd=" +
+                                std::to_string(v) + ",threads=" + std::to_string(plain.T);
     int rc = dnas_model_create_ex(fm, device_id, (size_t)1 << 30, options.c_str(), &t);
     if (rc != DNAS_OK) return DNAS_OK;          // (whatever is wrong will be reported by the creation that asked for this)
     for (int rep = 0; rep < 2 && rc == DNAS_OK; ++rep)
@@ -357,7 +360,7 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
       if (want != 'C' && wantG < 2) {
         const int threadsA = wantT ? wantT : dnas::kTierAThreads;
         if (wantFwd < 0 && autotune) {
-          int rcTune = tune_forwarded_rows(fm, device_id, threadsA, &wantFwd);
+          int rcTune = tune_forwarded_rows(fm, device_id, 1, threadsA, &wantFwd);
           if (rcTune != DNAS_OK) return bail(rcTune);
           if (hipSetDevice(device_id) != hipSuccess) return bail(dnas::fail(DNAS_E_DEVICE, "hipSetDevice failed"));
         }
@@ -368,7 +371,10 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
         whyNotA = "cluster forced";
       }
       if (!m->plan.ok && want != 'A') {
-        m->plan = dnas::chooseClusterPlan(*fm, wantG, wantT);
+        // (clusters are not tuned: on both machines that need them the program with F rows is slower -- 0.175 against 0.185
+        //  on the 46 670-state one, 0.048 against 0.068 on the 258 538-state one -- and planning them twice takes seconds;
+        //  plan_fwd=1 still asks for it)
+        m->plan = dnas::chooseClusterPlan(*fm, wantG, wantT, wantFwd < 0 ? 0 : wantFwd);
         if (!m->plan.ok) m->plan.whyNot = "one work-group: " + whyNotA + "; cluster: " + m->plan.whyNot;
       }
       if (!m->plan.ok) {
@@ -1157,18 +1163,19 @@ extern "C" int dnas_tierc_plan(const dnas_flat_model* fm, int32_t members, int32
 // Tier C diagnostics of the last call: clusters that ran, and how many of them had members on more than one XCD.
 // Analysis / test aid: the F rows of the tier-A plan (rows whose states are evaluated from the registers of the row above).
 // fwd_rows[rows][3] = {index among the F rows (0: not an F row), kind of the edges from above (1 emit, 2 null, 0 both), their
-// common score class or -1}; fwd_tab[n_words][threads]: 6 bits per F row and lane (layout: csrc/host/plan.cpp).
-extern "C" int dnas_tiera_plan_forwarded(const dnas_flat_model* fm, int32_t* fwd_rows, uint32_t* fwd_tab, size_t fwd_cap, int32_t* n_words) {
+// common score class or -1}; fwd_tab[members][n_words][threads]: 6 bits per F row and lane (layout: csrc/host/plan.cpp).
+extern "C" int dnas_tiera_plan_forwarded(const dnas_flat_model* fm, int32_t members, int32_t* fwd_rows, uint32_t* fwd_tab, size_t fwd_cap,
+                                         int32_t* n_words) {
   if (!fm || !n_words) return dnas::fail(DNAS_E_INVALID, "null argument");
   try {
-    const dnas::TierAPlan p = dnas::buildTierAPlan(*fm);
+    const dnas::TierAPlan p = members == 1 ? dnas::buildTierAPlan(*fm) : dnas::chooseClusterPlan(*fm, members, 0);
     if (!p.ok) return dnas::fail(DNAS_E_UNSUPPORTED, p.whyNot);
     *n_words = p.nFwdWords;
     if (fwd_rows)
       for (int k = 0; k < p.K; ++k) { fwd_rows[3 * k] = p.rows[k].fwd; fwd_rows[3 * k + 1] = p.rows[k].fkind; fwd_rows[3 * k + 2] = p.rows[k].fcls; }
     if (fwd_tab) {
-      if (fwd_cap < (size_t)p.nFwdWords * p.T) return dnas::fail(DNAS_E_INVALID, "forward table buffer too small");
-      memcpy(fwd_tab, p.fwdTab.data(), (size_t)p.nFwdWords * p.T * sizeof(uint32_t));
+      if (fwd_cap < (size_t)p.G * p.nFwdWords * p.T) return dnas::fail(DNAS_E_INVALID, "forward table buffer too small");
+      if (p.nFwdWords > 0) memcpy(fwd_tab, p.fwdTab.data(), (size_t)p.G * p.nFwdWords * p.T * sizeof(uint32_t));
     }
     return DNAS_OK;
   } catch (const std::exception& e) {

@@ -235,6 +235,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
     entTab += (size_t)member * kEntries * T;
     metaTab += (size_t)member * K * T;
     foldTab += (size_t)member * DNAS_GROWS * T;
+    fwdTab += (size_t)member * (DNAS_FWDWORDS > 0 ? DNAS_FWDWORDS : 1) * T;
     if (tid == 0) {
       unsigned xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));

@@ -189,12 +189,14 @@ int dnas_tierc_plan(const dnas_flat_model *fm, int32_t members, int32_t *info, i
                     size_t entries_cap, uint32_t *meta, int32_t *member_of, int32_t *lds_index, int32_t *lattice_slot,
                     uint32_t *fold);
 int dnas_model_cluster_census(dnas_model *model, int32_t *clusters, int32_t *split);
-/* Analysis / test aid: the F rows of the tier-A plan -- rows whose states have one in-edge, from the state in the row above
- * in the same thread, and are evaluated from that thread's registers instead of an LDS accumulator.  fwd_rows[rows][3] =
- * {index among the F rows (0: not one), kind of the edges from above (1 emit, 2 null, 0 both), common score class or -1};
- * fwd_tab[*n_words][threads]: per F row and lane 6 bits (bit 0 valid, bit 1 null edge, [2:4) class, [4:6) emitted base),
- * five rows to a word.  Outputs other than n_words may be NULL. */
-int dnas_tiera_plan_forwarded(const dnas_flat_model *fm, int32_t *fwd_rows, uint32_t *fwd_tab, size_t fwd_cap, int32_t *n_words);
+/* Analysis / test aid: the F rows of the plan (members = 1: tier A, else the tier-C plan as dnas_tierc_plan describes it) --
+ * rows whose states have one in-edge, from the state in the row above in the same thread, and are evaluated from that
+ * thread's registers instead of an LDS accumulator.  fwd_rows[rows][3] = {index among the F rows (0: not one), kind of the
+ * edges from above (1 emit, 2 null, 0 both), common score class or -1}; fwd_tab[members][*n_words][threads]: per F row and
+ * lane 6 bits (bit 0 valid, bit 1 null edge, [2:4) class, [4:6) emitted base), five rows to a word.  Outputs other than
+ * n_words may be NULL. */
+int dnas_tiera_plan_forwarded(const dnas_flat_model *fm, int32_t members, int32_t *fwd_rows, uint32_t *fwd_tab, size_t fwd_cap,
+                              int32_t *n_words);
 
 /* Analysis / test aid: where tier A puts each state (lds_index = row*threads + lane; lattice_slot = its
  * position inside a lattice row).  No GPU needed.  DNAS_E_UNSUPPORTED when the machine does not fit tier A. */
