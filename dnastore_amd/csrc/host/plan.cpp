@@ -54,6 +54,108 @@ std::vector<int> partitionStates(int N, const std::vector<Edge>& edges, const st
   return part;
 }
 
+// Pre-order of a depth-first walk over the out-edges (every state, roots in state order) and each state's parent in it.
+void depthFirstWalk(int N, const std::vector<Edge>& edges, const std::vector<std::vector<int>>& outOf, std::vector<int>* parent,
+                    std::vector<int>* walk) {
+  std::vector<int> pre((size_t)N, -1);
+  parent->assign((size_t)N, -1);
+  walk->clear();
+  walk->reserve((size_t)N);
+  int next = 0;
+  std::vector<std::pair<int, size_t>> stack;
+  for (int root = 0; root < N; ++root) {
+    if (pre[(size_t)root] >= 0) continue;
+    pre[(size_t)root] = next++;
+    walk->push_back(root);
+    stack.emplace_back(root, 0);
+    while (!stack.empty()) {
+      const int u = stack.back().first;
+      if (stack.back().second < outOf[(size_t)u].size()) {
+        const int v2 = edges[(size_t)outOf[(size_t)u][stack.back().second++]].dst;
+        if (pre[(size_t)v2] < 0) { pre[(size_t)v2] = next++; (*parent)[(size_t)v2] = u; walk->push_back(v2); stack.emplace_back(v2, 0); }
+      } else {
+        stack.pop_back();
+      }
+    }
+  }
+}
+
+// Lane placement inside each row.  Two goals.  (1) The waves of a work-group sweep without a
+// barrier and drift apart, so an edge into a later row is only CERTAIN to be relaxed in the
+// same sweep when source and destination belong to the same wave (a wave runs its rows in
+// order): a state goes to the wave of its "lead" -- the source in an earlier row it hangs on.
+// (2) LDS is 64 banks of 4 bytes and a 64-bit LDS operation is served in two 32-lane halves,
+// so a push is conflict-free when the 32 destination cells of a half fall on 32 different
+// bank pairs, i.e. have different (lane mod 32): best is the lead's own lane (the chain stays
+// inside one thread), then the other lane of that wave with the same residue, then any lane
+// of the wave whose half does not yet use that bank pair, then the same residue elsewhere.
+// Returns the lane of every state; rowMembers[(member * K + row)] lists the states of each row.
+std::vector<int> placeLanes(int N, int G, int K, int T, const std::vector<Edge>& edges, const std::vector<std::vector<int>>& inOf,
+                            const std::vector<int>& part, const std::vector<int>& rowOfState, const std::vector<int>& segOfRow,
+                            const std::vector<int>& attOf, std::vector<std::vector<int>>* rowMembersOut) {
+  std::vector<int> laneOf(N, -1);
+  std::vector<std::vector<int>>& rowMembers = *rowMembersOut;
+  rowMembers.assign((size_t)G * K, {});
+  auto bucket = [&](int j) { return (size_t)part[j] * K + rowOfState[j]; };
+  for (int j = 0; j < N; ++j) { laneOf[j] = (int)rowMembers[bucket(j)].size(); rowMembers[bucket(j)].push_back(j); }
+  auto leadOf = [&](int j) {
+    int any = -1;
+    for (int e : inOf[j]) {
+      const int s = edges[e].src;
+      if (s == j || part[s] != part[j]) continue;
+      if (rowOfState[s] < rowOfState[j]) return s;
+      if (any < 0) any = s;
+    }
+    return any;
+  };
+  for (int pass = 0; pass < 2; ++pass) {
+    for (size_t b = 0; b < rowMembers.size(); ++b) {
+      const std::vector<int>& mem = rowMembers[b];
+      if (mem.empty()) continue;          // padding row
+      const int n = (int)mem.size();
+      if (segOfRow[(int)(b % (size_t)K)] == 0) {          // an F row: every state sits in the lane of the state it hangs under
+        for (int j : mem) laneOf[j] = laneOf[attOf[j]];
+        continue;
+      }
+      std::vector<char> lanesFree(T, 1);
+      std::vector<int> newLane(n, -1), lead(n, -1);
+      std::vector<std::array<unsigned char, 32>> bankUse(T / 32);   // per 32-lane half: leads per bank pair
+      for (auto& h : bankUse) h.fill(0);
+      auto take = [&](int i, int t) { newLane[i] = t; lanesFree[t] = 0; if (lead[i] >= 0) ++bankUse[t / 32][laneOf[lead[i]] % 32]; };
+      for (int i = 0; i < n; ++i) lead[i] = leadOf(mem[i]);
+      for (int i = 0; i < n; ++i)          // the lead's own lane
+        if (lead[i] >= 0 && lanesFree[laneOf[lead[i]]]) take(i, laneOf[lead[i]]);
+      for (int i = 0; i < n; ++i) {        // same wave, same residue
+        if (newLane[i] >= 0 || lead[i] < 0) continue;
+        const int t = laneOf[lead[i]] ^ 32;
+        if (lanesFree[t]) take(i, t);
+      }
+      for (int i = 0; i < n; ++i) {        // same wave, a half that does not use this bank pair yet
+        if (newLane[i] >= 0 || lead[i] < 0) continue;
+        const int w0 = laneOf[lead[i]] & ~63, r = laneOf[lead[i]] % 32;
+        int bestT = -1, bestUse = 1 << 30;
+        for (int t = w0; t < w0 + 64; ++t)
+          if (lanesFree[t] && bankUse[t / 32][r] < bestUse) { bestUse = bankUse[t / 32][r]; bestT = t; }
+        if (bestT >= 0) take(i, bestT);
+      }
+      for (int i = 0; i < n; ++i) {        // another wave, same residue
+        if (newLane[i] >= 0 || lead[i] < 0) continue;
+        const int r = laneOf[lead[i]] % 32;
+        for (int t = r; t < T; t += 32)
+          if (lanesFree[t]) { take(i, t); break; }
+      }
+      int cursor = 0;
+      for (int i = 0; i < n; ++i) {
+        if (newLane[i] >= 0) continue;
+        while (!lanesFree[cursor]) ++cursor;
+        take(i, cursor);
+      }
+      for (int i = 0; i < n; ++i) laneOf[mem[i]] = newLane[i];
+    }
+  }
+  return laneOf;
+}
+
 TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const int forwardedRows = -1) {
   TierAPlan p;
   const int N = fm.n_states, D = fm.max_dup_len;
@@ -105,27 +207,8 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const i
   for (size_t e = 0; e < edges.size(); ++e) { outOf[edges[e].src].push_back((int)e); inOf[edges[e].dst].push_back((int)e); }
 
   // depth-first walk of the machine (the partition and the row dealing both follow it)
-  std::vector<int> pre(N, -1), parent(N, -1), walk;
-  walk.reserve(N);
-  {
-    int next = 0;
-    std::vector<std::pair<int, size_t>> stack;
-    for (int root = 0; root < N; ++root) {
-      if (pre[root] >= 0) continue;
-      pre[root] = next++;
-      walk.push_back(root);
-      stack.emplace_back(root, 0);
-      while (!stack.empty()) {
-        const int u = stack.back().first;
-        if (stack.back().second < outOf[u].size()) {
-          const int v2 = edges[outOf[u][stack.back().second++]].dst;
-          if (pre[v2] < 0) { pre[v2] = next++; parent[v2] = u; walk.push_back(v2); stack.emplace_back(v2, 0); }
-        } else {
-          stack.pop_back();
-        }
-      }
-    }
-  }
+  std::vector<int> parent, walk;
+  depthFirstWalk(N, edges, outOf, &parent, &walk);
 
   // ---- which member of the cluster owns which state.  A state with an in-edge from another member gets a slot in
   // its member's INBOX: cells of the cluster's exchange buffer that the other members offer into and that the
@@ -647,74 +730,9 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const i
     }
   }
 
-  // Lane placement inside each row.  Two goals.  (1) The waves of a work-group sweep without a
-  // barrier and drift apart, so an edge into a later row is only CERTAIN to be relaxed in the
-  // same sweep when source and destination belong to the same wave (a wave runs its rows in
-  // order): a state goes to the wave of its "lead" -- the source in an earlier row it hangs on.
-  // (2) LDS is 64 banks of 4 bytes and a 64-bit LDS operation is served in two 32-lane halves,
-  // so a push is conflict-free when the 32 destination cells of a half fall on 32 different
-  // bank pairs, i.e. have different (lane mod 32): best is the lead's own lane (the chain stays
-  // inside one thread), then the other lane of that wave with the same residue, then any lane
-  // of the wave whose half does not yet use that bank pair, then the same residue elsewhere.
-  std::vector<int> laneOf(N, -1);
-  std::vector<std::vector<int>> rowMembers((size_t)G * K);                    // states of each (member, row)
-  auto bucket = [&](int j) { return (size_t)part[j] * K + rowOfState[j]; };
-  for (int j = 0; j < N; ++j) { laneOf[j] = (int)rowMembers[bucket(j)].size(); rowMembers[bucket(j)].push_back(j); }
-  auto leadOf = [&](int j) {
-    int any = -1;
-    for (int e : inOf[j]) {
-      const int s = edges[e].src;
-      if (s == j || part[s] != part[j]) continue;
-      if (rowOfState[s] < rowOfState[j]) return s;
-      if (any < 0) any = s;
-    }
-    return any;
-  };
-  for (int pass = 0; pass < 2; ++pass) {
-    for (size_t b = 0; b < rowMembers.size(); ++b) {
-      const std::vector<int>& mem = rowMembers[b];
-      if (mem.empty()) continue;          // padding row
-      const int n = (int)mem.size();
-      if (segOfRow[(int)(b % (size_t)K)] == 0) {          // an F row: every state sits in the lane of the state it hangs under
-        for (int j : mem) laneOf[j] = laneOf[attOf[j]];
-        continue;
-      }
-      std::vector<char> lanesFree(T, 1);
-      std::vector<int> newLane(n, -1), lead(n, -1);
-      std::vector<std::array<unsigned char, 32>> bankUse(T / 32);   // per 32-lane half: leads per bank pair
-      for (auto& h : bankUse) h.fill(0);
-      auto take = [&](int i, int t) { newLane[i] = t; lanesFree[t] = 0; if (lead[i] >= 0) ++bankUse[t / 32][laneOf[lead[i]] % 32]; };
-      for (int i = 0; i < n; ++i) lead[i] = leadOf(mem[i]);
-      for (int i = 0; i < n; ++i)          // the lead's own lane
-        if (lead[i] >= 0 && lanesFree[laneOf[lead[i]]]) take(i, laneOf[lead[i]]);
-      for (int i = 0; i < n; ++i) {        // same wave, same residue
-        if (newLane[i] >= 0 || lead[i] < 0) continue;
-        const int t = laneOf[lead[i]] ^ 32;
-        if (lanesFree[t]) take(i, t);
-      }
-      for (int i = 0; i < n; ++i) {        // same wave, a half that does not use this bank pair yet
-        if (newLane[i] >= 0 || lead[i] < 0) continue;
-        const int w0 = laneOf[lead[i]] & ~63, r = laneOf[lead[i]] % 32;
-        int bestT = -1, bestUse = 1 << 30;
-        for (int t = w0; t < w0 + 64; ++t)
-          if (lanesFree[t] && bankUse[t / 32][r] < bestUse) { bestUse = bankUse[t / 32][r]; bestT = t; }
-        if (bestT >= 0) take(i, bestT);
-      }
-      for (int i = 0; i < n; ++i) {        // another wave, same residue
-        if (newLane[i] >= 0 || lead[i] < 0) continue;
-        const int r = laneOf[lead[i]] % 32;
-        for (int t = r; t < T; t += 32)
-          if (lanesFree[t]) { take(i, t); break; }
-      }
-      int cursor = 0;
-      for (int i = 0; i < n; ++i) {
-        if (newLane[i] >= 0) continue;
-        while (!lanesFree[cursor]) ++cursor;
-        take(i, cursor);
-      }
-      for (int i = 0; i < n; ++i) laneOf[mem[i]] = newLane[i];
-    }
-  }
+  // which lane of its row every state gets (placeLanes above)
+  std::vector<std::vector<int>> rowMembers;                    // states of each (member, row)
+  const std::vector<int> laneOf = placeLanes(N, G, K, T, edges, inOf, part, rowOfState, segOfRow, attOf, &rowMembers);
 
   // row shapes as used, S stripes
   p.rows.assign(K, RowShape{0, -1, -1, -2, 0, -1, 0, -1, -2});   // kind / cls / gOut: -1 / -2 / -1 = no entry seen yet
