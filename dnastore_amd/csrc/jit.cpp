@@ -61,10 +61,14 @@ std::string kernelCacheDir() {
 
 unsigned long long cacheHash(const std::string& text) { return (unsigned long long)fnv1a(tieraSource(), fnv1a(text + "|" DNAS_ARCH)); }
 
+// looked for in the kernel cache first, then among the records shipped with the library (<library dir>/tune/: the verdicts
+// for the fixture and bench machines, regenerated with tools/make_tune_records.sh whenever the kernel source changes)
 std::string cacheNoteRead(const std::string& name) {
-  std::ifstream in(kernelCacheDir() + "/" + name);
-  if (!in) return "";
-  return std::string((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+  for (const std::string& dir : {kernelCacheDir(), libraryDir() + "/tune"}) {
+    std::ifstream in(dir + "/" + name);
+    if (in) return std::string((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+  }
+  return "";
 }
 
 void cacheNoteWrite(const std::string& name, const std::string& text) {
