@@ -204,10 +204,8 @@ namespace {
 // water64.1*l4c4 -- and the plan's cost model does not predict it, so it is measured: when a model is first created for a
 // machine, both row programs are built, compiled and timed on a synthetic read (one work-group each), and the verdict is
 // kept next to the cached code objects (kcache/tune_<hash>.txt; the hash covers both plans and the kernel source).
-int tune_forwarded_rows(const dnas_flat_model* fm, int device_id, int members, int threads, int* choice) {
-  // members: 1 tier A; 0 / >= 2 tier C (the smallest cluster / that many work-groups per read)
-  *choice = 0;
-  // the machine's graph (not the error model: the row programs do not depend on it) names the record
+// the machine's graph (not the error model: the row programs do not depend on it) names the record
+std::string tune_record_name(const dnas_flat_model* fm, int members, int threads) {
   std::string graph((const char*)&fm->n_states, sizeof fm->n_states);
   auto add = [&](const void* ptr, size_t bytes) { graph.append((const char*)ptr, bytes); };
   add(&fm->max_dup_len, sizeof fm->max_dup_len); add(&threads, sizeof threads); add(&members, sizeof members);
@@ -217,6 +215,13 @@ int tune_forwarded_rows(const dnas_flat_model* fm, int device_id, int members, i
   add(fm->nin_score, (size_t)fm->n_null * sizeof(double));
   char name[64];
   snprintf(name, sizeof name, "tune_%016llx.txt", dnas::cacheHash(graph));
+  return name;
+}
+
+int tune_forwarded_rows(const dnas_flat_model* fm, int device_id, int members, int threads, int* choice) {
+  // members: 1 tier A; 0 / >= 2 tier C (the smallest cluster / that many work-groups per read)
+  *choice = 0;
+  const std::string name = tune_record_name(fm, members, threads);
   const std::string note = dnas::cacheNoteRead(name);
   if (!note.empty()) { *choice = note[0] == '1'; return DNAS_OK; }
   const dnas::TierAPlan plain = members == 1 ? dnas::buildTierAPlan(*fm, threads, 0) : dnas::chooseClusterPlan(*fm, members, threads, 0);
@@ -1066,7 +1071,14 @@ extern "C" int dnas_tiera_plan_tables(const dnas_flat_model* fm, int32_t* row_sh
 extern "C" int dnas_tiera_precompile(const dnas_flat_model* fm, char* note, size_t note_cap) {
   if (!fm) return dnas::fail(DNAS_E_INVALID, "null argument");
   try {
-    const dnas::TierAPlan p = dnas::buildTierAPlan(*fm);
+    // the row program a model of this machine will run: as the environment says, else as a recorded verdict says
+    // (tune_forwarded_rows), else the plain one
+    int fwd = -1;
+    if (!getenv("DNAS_PLAN_FWD")) {
+      const std::string rec = dnas::cacheNoteRead(tune_record_name(fm, 1, dnas::kTierAThreads));
+      fwd = !rec.empty() && rec[0] == '1' ? 1 : 0;
+    }
+    const dnas::TierAPlan p = dnas::buildTierAPlan(*fm, dnas::kTierAThreads, fwd);
     std::string msg;
     if (!p.ok) {
       msg = "tier B: " + p.whyNot;
