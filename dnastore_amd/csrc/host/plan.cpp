@@ -232,6 +232,39 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const i
   p.crossEdges = edges.empty() ? 0. : (double)nCross / (double)edges.size();
   for (int j = 0; j < N; ++j)
     if (parent[j] >= 0 && part[parent[j]] != part[j]) parent[j] = -1;   // the dealing follows a member's own subtrees
+  std::vector<std::vector<int>> walkOf(G);
+  for (int j : walk) walkOf[part[j]].push_back(j);
+  // The order the states are dealt in.  Depth first keeps a chain together; BREADTH first (inside each member, from the
+  // member's entry points in depth-first order) deals the states of one depth next to each other, so that what grows in
+  // the same sweep sits in the same rows and waves -- measured on MI355X: 0.556 against 0.538 of the roofline on
+  // s16h74l4c4 (13.8 sweeps per column against 14.2), 0.407 against 0.364 on water64.1*l4c4 (23 against 28).
+  bool breadthFirst = true;
+  if (const char* e = getenv("DNAS_PLAN_BFS")) breadthFirst = atoi(e) != 0;
+  if (breadthFirst) {
+    std::vector<char> seen((size_t)N, 0);
+    for (int g = 0; g < G; ++g) {
+      std::vector<int> order;
+      order.reserve(walkOf[g].size());
+      for (int root : walkOf[g]) {
+        if (seen[root]) continue;
+        seen[root] = 1;
+        parent[root] = -1;
+        size_t head = order.size();
+        order.push_back(root);
+        while (head < order.size()) {
+          const int u = order[head++];
+          for (int e : outOf[u]) {
+            const int v2 = edges[e].dst;
+            if (part[v2] != g || seen[v2]) continue;
+            seen[v2] = 1; parent[v2] = u; order.push_back(v2);
+          }
+        }
+      }
+      walkOf[g].swap(order);
+    }
+    walk.clear();
+    for (int g = 0; g < G; ++g) walk.insert(walk.end(), walkOf[g].begin(), walkOf[g].end());
+  }
   // ---- forwarded runs (forwardedRows / DNAS_PLAN_FWD; in a cluster: inside a member).  A state whose ONLY in-edge comes
   // from the state in the row right above it, in the same thread, needs no LDS accumulator, no read and no idle check: its
   // cells are a function of that thread's registers ("F rows" of the program; the kernel evaluates them from S and D of
@@ -262,8 +295,6 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const i
       }
     }
 
-  std::vector<std::vector<int>> walkOf(G);
-  for (int j : walk) walkOf[part[j]].push_back(j);
   int nInboxRows = 0;
   for (int g = 0; g < G; ++g) nInboxRows = std::max(nInboxRows, (inboxCount[g] + T - 1) / T);
   if (G > 1 && nInboxRows == 0) nInboxRows = 1;   // (a cluster whose members never talk: keep the kernel's shape)

@@ -67,6 +67,7 @@ struct TierAPlan {
   long exchangeCells() const { return (long)G * nGRows * T; }   // cells of one exchange array
 };
 
+constexpr int kPlanVersion = 2;      // bumped when the planner changes what it produces: recorded tuning verdicts name it
 constexpr int kTierAThreads = 1024;
 constexpr int kTierAMaxRows = 14;
 constexpr int kTierCMaxMembers = 32;                  // one XCD

@@ -209,6 +209,7 @@ std::string tune_record_name(const dnas_flat_model* fm, int members, int threads
   std::string graph((const char*)&fm->n_states, sizeof fm->n_states);
   auto add = [&](const void* ptr, size_t bytes) { graph.append((const char*)ptr, bytes); };
   add(&fm->max_dup_len, sizeof fm->max_dup_len); add(&threads, sizeof threads); add(&members, sizeof members);
+  add(&dnas::kPlanVersion, sizeof dnas::kPlanVersion);
   add(fm->ein_ptr, ((size_t)fm->n_states + 1) * sizeof(int32_t)); add(fm->ein_src, (size_t)fm->n_emit * sizeof(int32_t));
   add(fm->ein_score, (size_t)fm->n_emit * sizeof(double)); add(fm->ein_base, (size_t)fm->n_emit);
   add(fm->nin_ptr, ((size_t)fm->n_states + 1) * sizeof(int32_t)); add(fm->nin_src, (size_t)fm->n_null * sizeof(int32_t));
