@@ -322,14 +322,14 @@ def test_row_program_autotune(da, oracle_mod, ref_data, tmp_path, monkeypatch):
     assert got[0] == want[0] and np.array_equal(got[1].view(np.uint64), want[1].view(np.uint64)) and np.array_equal(got[2], want[2])
     for d in (tuned, again, plain):
         d.close()
-    # a machine with a shipped verdict (water64.1*l4c4: the program with F rows): nothing is timed, nothing is written
+    # a machine with a shipped verdict (dnastore_amd/tune/): nothing is timed, nothing is written
     water = da.Machine.compose(da.Machine.fromFile(os.path.join(ref_data, "water64.1.json")), da.Machine.fromFile(os.path.join(ref_data, "l4c4.json")))
     shipped = da.ViterbiDecoder(water, params)
-    forced = da.ViterbiDecoder(water, params, options="plan_fwd=1")
+    forced = [da.ViterbiDecoder(water, params, options="plan_fwd=%d" % v) for v in (0, 1)]
     assert [f for f in os.listdir(tmp_path) if f.startswith("tune_")] == notes
-    assert shipped.tier == forced.tier
+    assert shipped.tier in (forced[0].tier, forced[1].tier) and forced[0].tier != forced[1].tier
     wreads = [water.encodeBytes(bytes(range(8 * i, 8 * i + 8))) for i in range(3)]
-    a, b = shipped.decode(wreads), da.ViterbiDecoder(water, params, options="plan_fwd=0").decode(wreads)
-    assert a[0] == b[0] and np.array_equal(a[1].view(np.uint64), b[1].view(np.uint64))
-    shipped.close()
-    forced.close()
+    a, b, c = shipped.decode(wreads), forced[0].decode(wreads), forced[1].decode(wreads)
+    assert a[0] == b[0] == c[0] and np.array_equal(a[1].view(np.uint64), b[1].view(np.uint64)) and np.array_equal(a[1].view(np.uint64), c[1].view(np.uint64))
+    for d in [shipped] + forced:
+        d.close()
