@@ -192,6 +192,12 @@ class FlatModel:
         out["fwd_rows"], out["fwd_tab"] = fwd_rows, fwd_tab[:, :nw.value]
         return out
 
+    def tune_record_name(self, threads=0):
+        """File name of this machine's row-program tuning record (kernel cache / dnastore_amd/tune/)."""
+        buf = ctypes.create_string_buffer(64)
+        _l.check(_l.lib().dnas_tune_record_name(self.view, int(threads), buf, 64))
+        return buf.value.decode()
+
     def precompile_cluster(self, members=0):
         """JIT-specialise the cluster (tier C) fill kernel for this machine into the kernel cache (no GPU needed)."""
         buf = ctypes.create_string_buffer(4096)

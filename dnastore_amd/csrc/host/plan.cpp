@@ -156,7 +156,8 @@ std::vector<int> placeLanes(int N, int G, int K, int T, const std::vector<Edge>&
   return laneOf;
 }
 
-TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const int forwardedRows = -1) {
+TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const PlanChoice& choice = PlanChoice()) {
+  const int forwardedRows = choice.forwardedRows;
   TierAPlan p;
   const int N = fm.n_states, D = fm.max_dup_len;
   if (T != 1024 && T != 512) { TierAPlan bad; bad.whyNot = "work-groups of 512 or 1024 threads"; return bad; }
@@ -238,8 +239,67 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const i
   // member's entry points in depth-first order) deals the states of one depth next to each other, so that what grows in
   // the same sweep sits in the same rows and waves -- measured on MI355X: 0.556 against 0.538 of the roofline on
   // s16h74l4c4 (13.8 sweeps per column against 14.2), 0.407 against 0.364 on water64.1*l4c4 (23 against 28).
-  bool breadthFirst = true;
-  if (const char* e = getenv("DNAS_PLAN_BFS")) breadthFirst = atoi(e) != 0;
+  int orderVariant = choice.order;
+  if (orderVariant < 0) orderVariant = getenv("DNAS_PLAN_ORDER") ? atoi(getenv("DNAS_PLAN_ORDER")) : 1;
+  bool breadthFirst = orderVariant != 0;
+  if (breadthFirst && (orderVariant == 2 || orderVariant == 3)) {
+    // Longest-path layering (order 2).  Back edges = edges to a state that is still on the depth-first stack; over the
+    // rest (a DAG) a state's level is 1 + the highest level of its predecessors, and it is dealt after all of them, right
+    // behind the deepest one.  (3, an experiment: forward = towards a greater breadth-first depth; behaves like order 1.)
+    std::vector<int> pos((size_t)N, 0);
+    for (size_t i = 0; i < walk.size(); ++i) pos[walk[i]] = (int)i;
+    // post-order numbers tell ancestors: u is an ancestor of v iff pre[u] <= pre[v] and post[u] >= post[v]
+    std::vector<int> last((size_t)N, 0);      // last preorder index inside the subtree
+    for (size_t i = walk.size(); i-- > 0;) {
+      const int v = walk[i];
+      last[v] = std::max(last[v], (int)i);
+      // (parent[] here is still the depth-first parent, restricted to the member)
+    }
+    std::vector<int> dfsParent(parent);
+    for (size_t i = walk.size(); i-- > 0;) { const int v = walk[i]; if (dfsParent[v] >= 0) last[dfsParent[v]] = std::max(last[dfsParent[v]], last[v]); }
+    // variant 3: an edge is a forward edge when it leads to a greater breadth-first depth
+    std::vector<int> bfsDepth((size_t)N, -1);
+    if (orderVariant == 3) {
+      std::vector<int> q;
+      for (int root : walk) {
+        if (bfsDepth[root] >= 0) continue;
+        bfsDepth[root] = 0;
+        size_t h = q.size();
+        q.push_back(root);
+        while (h < q.size()) {
+          const int u = q[h++];
+          for (int ei : outOf[u]) { const int v = edges[ei].dst; if (part[v] == part[u] && bfsDepth[v] < 0) { bfsDepth[v] = bfsDepth[u] + 1; q.push_back(v); } }
+        }
+      }
+    }
+    auto isBack = [&](const Edge& e) {
+      if (orderVariant == 3) return bfsDepth[e.dst] <= bfsDepth[e.src];
+      return part[e.src] == part[e.dst] && pos[e.dst] <= pos[e.src] && last[e.dst] >= pos[e.src];
+    };
+    std::vector<int> level((size_t)N, 0), indeg((size_t)N, 0);
+    for (const Edge& e : edges) if (part[e.src] == part[e.dst] && !isBack(e) && e.src != e.dst) ++indeg[e.dst];
+    std::vector<int> ready;
+    for (int j : walk) if (indeg[j] == 0) ready.push_back(j);
+    std::vector<int> topo;
+    for (size_t h = 0; h < ready.size(); ++h) {
+      const int u = ready[h];
+      topo.push_back(u);
+      for (int ei : outOf[u]) {
+        const Edge& e = edges[ei];
+        if (part[e.src] != part[e.dst] || isBack(e) || e.src == e.dst) continue;
+        if (level[u] + 1 > level[e.dst]) { level[e.dst] = level[u] + 1; parent[e.dst] = u; }
+        if (--indeg[e.dst] == 0) ready.push_back(e.dst);
+      }
+    }
+    if ((int)topo.size() == N) {
+      std::stable_sort(topo.begin(), topo.end(), [&](int a2, int b2) { return level[a2] < level[b2]; });
+      for (int g = 0; g < G; ++g) walkOf[g].clear();
+      for (int j : topo) walkOf[part[j]].push_back(j);
+      for (int j = 0; j < N; ++j) if (level[j] == 0) parent[j] = -1;
+      walk = topo;
+    }
+    breadthFirst = false;
+  }
   if (breadthFirst) {
     std::vector<char> seen((size_t)N, 0);
     for (int g = 0; g < G; ++g) {
@@ -914,18 +974,18 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const i
 
 }  // namespace
 
-TierAPlan buildTierAPlan(const dnas_flat_model& fm, int threads, int forwardedRows) { return buildPlan(fm, 1, threads, forwardedRows); }
+TierAPlan buildTierAPlan(const dnas_flat_model& fm, int threads, const PlanChoice& choice) { return buildPlan(fm, 1, threads, choice); }
 
-TierAPlan buildClusterPlan(const dnas_flat_model& fm, int G, int threads, int forwardedRows) {
+TierAPlan buildClusterPlan(const dnas_flat_model& fm, int G, int threads, const PlanChoice& choice) {
   if (G < 2) { TierAPlan p; p.whyNot = "a cluster has at least two members"; return p; }
-  return buildPlan(fm, G, threads, forwardedRows);
+  return buildPlan(fm, G, threads, choice);
 }
 
-TierAPlan buildSmallestClusterPlan(const dnas_flat_model& fm, int gMin, int threads, int forwardedRows) {
+TierAPlan buildSmallestClusterPlan(const dnas_flat_model& fm, int gMin, int threads, const PlanChoice& choice) {
   TierAPlan last;
   const int lo = std::max(2, std::max(gMin, (int)(((long)fm.n_states * 100 / 93 + (long)kTierAMaxRows * kTierAThreads - 1) / ((long)kTierAMaxRows * kTierAThreads))));
   for (int G = lo; G <= kTierCMaxMembers; ++G) {
-    last = buildPlan(fm, G, threads, forwardedRows);
+    last = buildPlan(fm, G, threads, choice);
     if (last.ok) return last;
   }
   if (last.whyNot.empty()) last.whyNot = "more than " + std::to_string(kTierCMaxMembers) + " work-groups per read";
@@ -935,8 +995,8 @@ TierAPlan buildSmallestClusterPlan(const dnas_flat_model& fm, int gMin, int thre
 // Tier C as the runtime asks for it: members = 0 -> the smallest cluster; threads = 0 -> work-groups of 512 threads
 // (8 waves of 256 registers, twice the rows per thread: no register spills, and the machine fits fewer CUs) when that
 // needs no more work-groups per read than 1024-thread ones (measured faster at equal size), else 1024.
-TierAPlan chooseClusterPlan(const dnas_flat_model& fm, int members, int threads, int forwardedRows) {
-  auto build = [&](int t) { return members >= 2 ? buildClusterPlan(fm, members, t, forwardedRows) : buildSmallestClusterPlan(fm, 2, t, forwardedRows); };
+TierAPlan chooseClusterPlan(const dnas_flat_model& fm, int members, int threads, const PlanChoice& choice) {
+  auto build = [&](int t) { return members >= 2 ? buildClusterPlan(fm, members, t, choice) : buildSmallestClusterPlan(fm, 2, t, choice); };
   if (threads == 512 || threads == 1024) return build(threads);
   TierAPlan narrow = build(512);
   // both shapes hold the same number of states per work-group: when the narrow one already gets by with the fewest

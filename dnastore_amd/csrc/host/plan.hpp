@@ -67,7 +67,20 @@ struct TierAPlan {
   long exchangeCells() const { return (long)G * nGRows * T; }   // cells of one exchange array
 };
 
-constexpr int kPlanVersion = 2;      // bumped when the planner changes what it produces: recorded tuning verdicts name it
+constexpr int kPlanVersion = 3;      // bumped when the planner changes what it produces: recorded tuning verdicts name it
+
+// What the caller (the runtime's tuning run, an option, an experiment) decides about the row program; -1: as the
+// environment says (DNAS_PLAN_FWD, DNAS_PLAN_ORDER), else the default.
+//   forwardedRows  1: with F rows (states evaluated from the registers of the row above), 0: without (default)
+//   order          the order the states are dealt onto the program in: 0 depth first, 1 breadth first (default: what grows in
+//                  the same sweep sits in the same rows and waves), 2 by longest-path level over the machine without the
+//                  edges that close a cycle of the depth-first walk (a state is dealt after ALL its forward predecessors).
+//                  Which of 1 and 2 is faster depends on the machine (s16h74l4c4: 0.565 / 0.581 of the roofline,
+//                  water64.1*l4c4: 0.405 / 0.367); the runtime times them (option autotune).
+struct PlanChoice {
+  int forwardedRows = -1;
+  int order = -1;
+};
 constexpr int kTierAThreads = 1024;
 constexpr int kTierAMaxRows = 14;
 constexpr int kTierCMaxMembers = 32;                  // one XCD
@@ -75,14 +88,12 @@ constexpr size_t kTierALdsLimit = 160 * 1024 - 1024;  // leave room for the stat
 
 // One work-group per read; fails (ok = false) when the machine does not fit one CU.
 // threads: 1024 (16 waves of 128 registers) or 512 (8 waves of 256 registers, twice the rows per thread).
-// forwardedRows: 1 a row program with F rows (states evaluated from the registers of the row above), 0 without,
-// -1 as the environment says (DNAS_PLAN_FWD, default without).
-TierAPlan buildTierAPlan(const dnas_flat_model& fm, int threads = kTierAThreads, int forwardedRows = -1);
+TierAPlan buildTierAPlan(const dnas_flat_model& fm, int threads = kTierAThreads, const PlanChoice& choice = PlanChoice());
 // G work-groups per read (G >= 2); fails when the states do not fit G CUs or no common row program exists.
-TierAPlan buildClusterPlan(const dnas_flat_model& fm, int G, int threads = kTierAThreads, int forwardedRows = -1);
+TierAPlan buildClusterPlan(const dnas_flat_model& fm, int G, int threads = kTierAThreads, const PlanChoice& choice = PlanChoice());
 // The smallest cluster that fits (tries G = gMin .. kTierCMaxMembers).
-TierAPlan buildSmallestClusterPlan(const dnas_flat_model& fm, int gMin = 2, int threads = kTierAThreads, int forwardedRows = -1);
+TierAPlan buildSmallestClusterPlan(const dnas_flat_model& fm, int gMin = 2, int threads = kTierAThreads, const PlanChoice& choice = PlanChoice());
 // What the runtime uses for tier C: members = 0 -> smallest cluster, threads = 0 -> 512 when that needs fewer members.
-TierAPlan chooseClusterPlan(const dnas_flat_model& fm, int members, int threads, int forwardedRows = -1);
+TierAPlan chooseClusterPlan(const dnas_flat_model& fm, int members, int threads, const PlanChoice& choice = PlanChoice());
 
 }  // namespace dnas

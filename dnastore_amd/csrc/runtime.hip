@@ -219,24 +219,53 @@ std::string tune_record_name(const dnas_flat_model* fm, int members, int threads
   return name;
 }
 
-int tune_forwarded_rows(const dnas_flat_model* fm, int device_id, int members, int threads, int* choice) {
-  // members: 1 tier A; 0 / >= 2 tier C (the smallest cluster / that many work-groups per read)
-  *choice = 0;
-  const std::string name = tune_record_name(fm, members, threads);
-  const std::string note = dnas::cacheNoteRead(name);
-  if (!note.empty()) { *choice = note[0] == '1'; return DNAS_OK; }
-  const dnas::TierAPlan plain = members == 1 ? dnas::buildTierAPlan(*fm, threads, 0) : dnas::chooseClusterPlan(*fm, members, threads, 0);
-  const dnas::TierAPlan fwd = members == 1 ? dnas::buildTierAPlan(*fm, threads, 1) : dnas::chooseClusterPlan(*fm, members, threads, 1);
-  if (!plain.ok || !fwd.ok || fwd.nFwdRows == 0 || fwd.G != plain.G) {
-    if (plain.ok) dnas::cacheNoteWrite(name, "0  (no row program with forwarded rows for this machine)\n");
-    return DNAS_OK;
-  }
-  // four copies of a pseudo-random read of 160 bases: four work-groups, a few milliseconds per program
-  const int L = 160, nReads = 4;
+// "order=<o> fwd=<f> ..." -> the choice a record names (false: no record / not readable)
+bool parse_plan_record(const std::string& note, dnas::PlanChoice* choice) {
+  int o = -1, f = -1;
+  if (sscanf(note.c_str(), "order=%d fwd=%d", &o, &f) != 2 || o < 0 || o > 2 || f < 0 || f > 1) return false;
+  choice->order = o;
+  choice->forwardedRows = f;
+  return true;
+}
+
+// Which row program serves this machine fastest?  The planner can deal the states breadth first or by longest-path level,
+// with or without F rows (host/plan.hpp: PlanChoice); which is best depends on the machine and the plan's cost model does
+// not predict it, so it is measured: when a model is first created for a tier-A machine, the candidates are built, compiled
+// and timed on synthetic reads (one work-group each), and the verdict is kept next to the cached code objects
+// (kcache/tune_<hash>.txt; dnastore_amd/tune/ ships the verdicts of the fixture and bench machines).
+int tune_row_program(const dnas_flat_model* fm, int device_id, int threads, dnas::PlanChoice* choice) {
+  *choice = dnas::PlanChoice{0, 1};
+  const std::string name = tune_record_name(fm, 1, threads);
+  if (parse_plan_record(dnas::cacheNoteRead(name), choice)) return DNAS_OK;
+  // 240 reads of 480 bases of the kind the machine is for: what a random walk through the machine emits (a code word
+  // sequence), with one base in a hundred substituted -- one work-group per CU, about ten milliseconds per program.  (Random
+  // bases would do for a timing, but the programs differ in how a column's values spread, and that depends on the read; and
+  // four work-groups alone on the GPU do not show what a full launch shows: 6.18 against 6.15 ms there, 46.9 against 45.5 ms
+  // per 720-read launch for the two dealing orders on s16h74l4c4.)
+  const int L = 480, nReads = 240;
   std::vector<uint8_t> bases((size_t)L * nReads);
-  unsigned long long x = 88172645463325252ull;
-  for (int i = 0; i < L; ++i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; bases[(size_t)i] = (uint8_t)(x & 3); }
-  for (int r = 1; r < nReads; ++r) std::copy(bases.begin(), bases.begin() + L, bases.begin() + (size_t)r * L);
+  {
+    // (destination, emitted base or -1); the walk stays inside one message: it does not take an edge that reads the
+    // end-of-message symbol '$' while another one is there
+    std::vector<std::vector<std::pair<int, int>>> out((size_t)fm->n_states), outEnd((size_t)fm->n_states);
+    for (int j = 0; j < fm->n_states; ++j) {
+      for (int e = fm->ein_ptr[j]; e < fm->ein_ptr[j + 1]; ++e) (fm->ein_in[e] == '$' ? outEnd : out)[(size_t)fm->ein_src[e]].emplace_back(j, (int)fm->ein_base[e]);
+      for (int e = fm->nin_ptr[j]; e < fm->nin_ptr[j + 1]; ++e) (fm->nin_in[e] == '$' ? outEnd : out)[(size_t)fm->nin_src[e]].emplace_back(j, -1);
+    }
+    for (int j = 0; j < fm->n_states; ++j) if (out[(size_t)j].empty()) out[(size_t)j] = outEnd[(size_t)j];
+    unsigned long long x = 88172645463325252ull;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    for (int r = 0; r < nReads; ++r) {
+      int state = 0, got = 0;
+      for (long steps = 0; got < L && steps < 64l * L; ++steps) {
+        if (out[(size_t)state].empty()) { state = 0; continue; }
+        const std::pair<int, int>& e = out[(size_t)state][rnd() % out[(size_t)state].size()];
+        state = e.first;
+        if (e.second >= 0) bases[(size_t)r * L + got++] = (uint8_t)((rnd() % 100 == 0) ? (e.second + 1 + rnd() % 3) & 3 : e.second);
+      }
+      for (; got < L; ++got) bases[(size_t)r * L + got] = (uint8_t)(rnd() & 3);       // (a machine that emits too little)
+    }
+  }
   std::vector<uint64_t> readOff(nReads + 1), outOff(nReads + 1);
   const size_t cap = 4 * (size_t)L + 64;
   for (int r = 0; r <= nReads; ++r) { readOff[(size_t)r] = (uint64_t)r * L; outOff[(size_t)r] = (uint64_t)r * cap; }
@@ -244,25 +273,39 @@ int tune_forwarded_rows(const dnas_flat_model* fm, int device_id, int members, i
   std::vector<uint32_t> len(nReads);
   std::vector<double> ll(nReads);
   std::vector<uint8_t> st(nReads);
-  double ms[2] = {0, 0};
-  for (int v = 0; v < 2; ++v) {
+  // the default first: another candidate has to beat it by 1.5 % (run-to-run differences of one program stay below 0.5 %)
+  const dnas::PlanChoice candidates[] = {{0, 1}, {0, 2}, {1, 1}};
+  double best = 0;
+  std::string report;
+  for (const dnas::PlanChoice& c : candidates) {
+    if (c.forwardedRows) {
+      const dnas::TierAPlan p = dnas::buildTierAPlan(*fm, threads, c);
+      if (!p.ok || p.nFwdRows == 0) continue;           // no such program for this machine
+    }
     dnas_model* t = nullptr;
-    const std::string options = (members == 1 ? std::string("tier=A") : "tier=C,cluster=" + std::to_string(plain.G)) + ",autotune=0,plan_fwd=" +
-                                std::to_string(v) + ",threads=" + std::to_string(plain.T);
-    int rc = dnas_model_create_ex(fm, device_id, (size_t)1 << 30, options.c_str(), &t);
-    if (rc != DNAS_OK) return DNAS_OK;          // (whatever is wrong will be reported by the creation that asked for this)
-    for (int rep = 0; rep < 2 && rc == DNAS_OK; ++rep)
-      rc = dnas_viterbi_batch(t, nReads, readOff.data(), bases.data(), sym.data(), outOff.data(), len.data(), ll.data(), st.data());
+    const std::string options = "tier=A,autotune=0,plan_order=" + std::to_string(c.order) + ",plan_fwd=" + std::to_string(c.forwardedRows) +
+                                ",threads=" + std::to_string(threads);
+    int rc = dnas_model_create_ex(fm, device_id, (size_t)64 << 30, options.c_str(), &t);
+    if (rc != DNAS_OK) { if (c.order == 1 && !c.forwardedRows) return DNAS_OK; continue; }   // (the creation that asked reports what is wrong)
     dnas_batch_stats s{};
-    if (rc == DNAS_OK) rc = dnas_model_last_stats(t, &s);
+    double fastest = 0;
+    for (int rep = 0; rep < 3 && rc == DNAS_OK; ++rep) {          // the first run warms up; the faster of the other two counts
+      rc = dnas_viterbi_batch(t, nReads, readOff.data(), bases.data(), sym.data(), outOff.data(), len.data(), ll.data(), st.data());
+      if (rc == DNAS_OK) rc = dnas_model_last_stats(t, &s);
+      if (rc == DNAS_OK && rep > 0 && (fastest == 0 || s.fill_ms < fastest)) fastest = s.fill_ms;
+    }
     dnas_model_destroy(t);
-    if (rc != DNAS_OK) return DNAS_OK;
-    ms[v] = s.fill_ms;
+    s.fill_ms = fastest;
+    if (rc != DNAS_OK || !(s.fill_ms > 0)) continue;
+    char item[96];
+    snprintf(item, sizeof item, "  order=%d fwd=%d: %.3f ms", c.order, c.forwardedRows, s.fill_ms);
+    report += item;
+    if (best == 0 || s.fill_ms < 0.985 * best) { if (best == 0 || s.fill_ms < best) best = s.fill_ms; *choice = c; }
   }
-  *choice = ms[1] > 0 && ms[1] < 0.97 * ms[0] ? 1 : 0;
-  char text[256];
-  snprintf(text, sizeof text, "%d  plain rows %.3f ms, forwarded rows %.3f ms (fill of %d synthetic reads of %d bases)\n", *choice, ms[0], ms[1], nReads, L);
-  dnas::cacheNoteWrite(name, text);
+  if (best == 0) return DNAS_OK;
+  char head[160];
+  snprintf(head, sizeof head, "order=%d fwd=%d   (fill of %d synthetic reads of %d bases;", choice->order, choice->forwardedRows, nReads, L);
+  dnas::cacheNoteWrite(name, std::string(head) + report + ")\n");
   return DNAS_OK;
 }
 
@@ -282,7 +325,8 @@ extern "C" int dnas_model_create(const dnas_flat_model* fm, int device_id, size_
 
 // options: "key=value,key=value"; keys tier (A|B|C), cluster (work-groups per read), threads (512 | 1024 per work-group),
 // max_clusters, max_slots, cluster_timeout_s, persistent, traceback, arena_fraction, checkpoint, segment, plan_fwd (row program
-// with F rows: 0 | 1), autotune (0: do not time the two row programs when plan_fwd is not given).  A key that is absent falls back to the environment variable DNAS_<KEY>.
+// with F rows: 0 | 1), plan_order (dealing order: 0 depth first, 1 breadth first, 2 longest-path levels), autotune (0: do not
+// time the candidate row programs when neither is given).  A key that is absent falls back to the environment variable DNAS_<KEY>.
 extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, size_t arena_bytes, const char* options,
                                     dnas_model** out) {
   if (!fm || !out) return dnas::fail(DNAS_E_INVALID, "dnas_model_create: null argument");
@@ -353,11 +397,13 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
     const char* forceOpt = opt("tier");
     const std::string force = forceOpt ? forceOpt : "";
     const char want = !force.empty() ? (char)(force[0] & ~0x20) : 0;
-    int wantG = 0, wantT = 0, wantFwd = -1;
+    int wantG = 0, wantT = 0;
+    dnas::PlanChoice want_;               // -1: not said
     bool autotune = true;
     if (const char* s = opt("cluster")) wantG = atoi(s);
     if (const char* s = opt("threads")) wantT = atoi(s);
-    if (const char* s = opt("plan_fwd")) wantFwd = atoi(s) != 0;
+    if (const char* s = opt("plan_fwd")) want_.forwardedRows = atoi(s) != 0;
+    if (const char* s = opt("plan_order")) want_.order = std::max(0, std::min(2, atoi(s)));
     if (const char* s = opt("autotune")) autotune = atoi(s) != 0;
     if (want == 'B') {
       m->tierNote = "tier B forced by DNAS_TIER";
@@ -365,12 +411,13 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
       std::string whyNotA;
       if (want != 'C' && wantG < 2) {
         const int threadsA = wantT ? wantT : dnas::kTierAThreads;
-        if (wantFwd < 0 && autotune) {
-          int rcTune = tune_forwarded_rows(fm, device_id, 1, threadsA, &wantFwd);
+        dnas::PlanChoice choiceA = want_;
+        if (want_.forwardedRows < 0 && want_.order < 0 && autotune) {
+          int rcTune = tune_row_program(fm, device_id, threadsA, &choiceA);
           if (rcTune != DNAS_OK) return bail(rcTune);
           if (hipSetDevice(device_id) != hipSuccess) return bail(dnas::fail(DNAS_E_DEVICE, "hipSetDevice failed"));
         }
-        m->plan = dnas::buildTierAPlan(*fm, threadsA, wantFwd < 0 ? 0 : wantFwd);
+        m->plan = dnas::buildTierAPlan(*fm, threadsA, choiceA);
         if (!m->plan.ok) whyNotA = m->plan.whyNot;
       } else {
         m->plan.ok = false;
@@ -380,7 +427,7 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
         // (clusters are not tuned: on both machines that need them the program with F rows is slower -- 0.175 against 0.185
         //  on the 46 670-state one, 0.048 against 0.068 on the 258 538-state one -- and planning them twice takes seconds;
         //  plan_fwd=1 still asks for it)
-        m->plan = dnas::chooseClusterPlan(*fm, wantG, wantT, wantFwd < 0 ? 0 : wantFwd);
+        m->plan = dnas::chooseClusterPlan(*fm, wantG, wantT, want_);
         if (!m->plan.ok) m->plan.whyNot = "one work-group: " + whyNotA + "; cluster: " + m->plan.whyNot;
       }
       if (!m->plan.ok) {
@@ -1074,12 +1121,10 @@ extern "C" int dnas_tiera_precompile(const dnas_flat_model* fm, char* note, size
   try {
     // the row program a model of this machine will run: as the environment says, else as a recorded verdict says
     // (tune_forwarded_rows), else the plain one
-    int fwd = -1;
-    if (!getenv("DNAS_PLAN_FWD")) {
-      const std::string rec = dnas::cacheNoteRead(tune_record_name(fm, 1, dnas::kTierAThreads));
-      fwd = !rec.empty() && rec[0] == '1' ? 1 : 0;
-    }
-    const dnas::TierAPlan p = dnas::buildTierAPlan(*fm, dnas::kTierAThreads, fwd);
+    dnas::PlanChoice choice;
+    if (!getenv("DNAS_PLAN_FWD") && !getenv("DNAS_PLAN_ORDER"))
+      (void)parse_plan_record(dnas::cacheNoteRead(tune_record_name(fm, 1, dnas::kTierAThreads)), &choice);
+    const dnas::TierAPlan p = dnas::buildTierAPlan(*fm, dnas::kTierAThreads, choice);
     std::string msg;
     if (!p.ok) {
       msg = "tier B: " + p.whyNot;
@@ -1174,6 +1219,16 @@ extern "C" int dnas_tierc_plan(const dnas_flat_model* fm, int32_t members, int32
 }
 
 // Tier C diagnostics of the last call: clusters that ran, and how many of them had members on more than one XCD.
+// The name of the tuning record of a tier-A machine (tune_row_program above; tools/make_tune_records.py writes the records
+// that ship with the library from bench-like reads).
+extern "C" int dnas_tune_record_name(const dnas_flat_model* fm, int32_t threads, char* out, size_t cap) {
+  if (!fm || !out || cap < 40) return dnas::fail(DNAS_E_INVALID, "dnas_tune_record_name: bad argument");
+  const std::string name = tune_record_name(fm, 1, threads > 0 ? threads : dnas::kTierAThreads);
+  strncpy(out, name.c_str(), cap - 1);
+  out[cap - 1] = 0;
+  return DNAS_OK;
+}
+
 // Analysis / test aid: the F rows of the tier-A plan (rows whose states are evaluated from the registers of the row above).
 // fwd_rows[rows][3] = {index among the F rows (0: not an F row), kind of the edges from above (1 emit, 2 null, 0 both), their
 // common score class or -1}; fwd_tab[members][n_words][threads]: 6 bits per F row and lane (layout: csrc/host/plan.cpp).

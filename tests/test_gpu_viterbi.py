@@ -313,11 +313,11 @@ def test_row_program_autotune(da, oracle_mod, ref_data, tmp_path, monkeypatch):
     notes = [f for f in os.listdir(tmp_path) if f.startswith("tune_")]
     assert len(notes) == 1
     verdict = open(os.path.join(tmp_path, notes[0])).read()
-    assert verdict[0] in "01"
+    assert verdict.startswith("order=") and " fwd=" in verdict
     got = tuned.decode(reads)
     again = da.ViterbiDecoder(m, params)                           # reads the record: no second one appears
     assert [f for f in os.listdir(tmp_path) if f.startswith("tune_")] == notes and again.tier == tuned.tier
-    plain = da.ViterbiDecoder(m, params, options="plan_fwd=0")
+    plain = da.ViterbiDecoder(m, params, options="plan_fwd=0,plan_order=1")
     want = plain.decode(reads)
     assert got[0] == want[0] and np.array_equal(got[1].view(np.uint64), want[1].view(np.uint64)) and np.array_equal(got[2], want[2])
     for d in (tuned, again, plain):
@@ -325,9 +325,9 @@ def test_row_program_autotune(da, oracle_mod, ref_data, tmp_path, monkeypatch):
     # a machine with a shipped verdict (dnastore_amd/tune/): nothing is timed, nothing is written
     water = da.Machine.compose(da.Machine.fromFile(os.path.join(ref_data, "water64.1.json")), da.Machine.fromFile(os.path.join(ref_data, "l4c4.json")))
     shipped = da.ViterbiDecoder(water, params)
-    forced = [da.ViterbiDecoder(water, params, options="plan_fwd=%d" % v) for v in (0, 1)]
+    forced = [da.ViterbiDecoder(water, params, options="plan_fwd=0,plan_order=%d" % v) for v in (1, 2)]
     assert [f for f in os.listdir(tmp_path) if f.startswith("tune_")] == notes
-    assert shipped.tier in (forced[0].tier, forced[1].tier) and forced[0].tier != forced[1].tier
+    assert forced[0].tier != forced[1].tier
     wreads = [water.encodeBytes(bytes(range(8 * i, 8 * i + 8))) for i in range(3)]
     a, b, c = shipped.decode(wreads), forced[0].decode(wreads), forced[1].decode(wreads)
     assert a[0] == b[0] == c[0] and np.array_equal(a[1].view(np.uint64), b[1].view(np.uint64)) and np.array_equal(a[1].view(np.uint64), c[1].view(np.uint64))

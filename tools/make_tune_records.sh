@@ -2,7 +2,5 @@
 # On a GPU box (from the repository root):  bash tools/make_tune_records.sh   -> gpurun_out/tune_records/tune_*.txt ;
 # then, back home:  rm -f dnastore_amd/tune/tune_*.txt && cp gpurun_out/tune_records/tune_*.txt dnastore_amd/tune/
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-mkdir -p $R/gpurun_out/tune_records
-rm -f $R/gpurun_out/tune_records/*
-DNAS_KCACHE_DIR=$R/gpurun_out/tune_records python3 $R/tools/make_tune_records.py
-rm -f $R/gpurun_out/tune_records/*.hsaco
+rm -rf $R/gpurun_out/tune_records
+python3 $R/tools/make_tune_records.py $R/gpurun_out/tune_records
