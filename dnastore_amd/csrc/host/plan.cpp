@@ -292,6 +292,25 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const P
       }
     }
     if ((int)topo.size() == N) {
+      // A state may sit anywhere between its earliest level (above) and its latest (the deepest level minus the longest
+      // forward path below it); `slack` eighths of that room are used, i.e. the state moves towards the states it feeds.
+      int slackShare = choice.slack;
+      if (slackShare < 0) slackShare = getenv("DNAS_PLAN_SLACK") ? atoi(getenv("DNAS_PLAN_SLACK")) : 0;
+      slackShare = std::max(0, std::min(8, slackShare));
+      if (slackShare > 0) {
+        std::vector<int> down((size_t)N, 0);
+        int deepest = 0;
+        for (size_t i = topo.size(); i-- > 0;) {
+          const int u = topo[i];
+          for (int ei : outOf[u]) {
+            const Edge& e = edges[ei];
+            if (part[e.src] != part[e.dst] || isBack(e) || e.src == e.dst) continue;
+            down[u] = std::max(down[u], down[e.dst] + 1);
+          }
+          deepest = std::max(deepest, level[u]);
+        }
+        for (int j = 0; j < N; ++j) { const int room = std::max(0, deepest - down[j] - level[j]); level[j] += room * slackShare / 8; }
+      }
       std::stable_sort(topo.begin(), topo.end(), [&](int a2, int b2) { return level[a2] < level[b2]; });
       for (int g = 0; g < G; ++g) walkOf[g].clear();
       for (int j : topo) walkOf[part[j]].push_back(j);

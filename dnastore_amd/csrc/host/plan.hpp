@@ -77,9 +77,12 @@ constexpr int kPlanVersion = 3;      // bumped when the planner changes what it 
 //                  edges that close a cycle of the depth-first walk (a state is dealt after ALL its forward predecessors).
 //                  Which of 1 and 2 is faster depends on the machine (s16h74l4c4: 0.565 / 0.581 of the roofline,
 //                  water64.1*l4c4: 0.405 / 0.367); the runtime times them (option autotune).
+//   slack          order 2 only: how far (in eighths, 0 .. 8) a state moves from its earliest level towards its latest one
+//                  (DNAS_PLAN_SLACK; s16h74l4c4: 0.573 of the roofline at 0, 0.599 at 8)
 struct PlanChoice {
   int forwardedRows = -1;
   int order = -1;
+  int slack = -1;
 };
 constexpr int kTierAThreads = 1024;
 constexpr int kTierAMaxRows = 14;

@@ -221,10 +221,11 @@ std::string tune_record_name(const dnas_flat_model* fm, int members, int threads
 
 // "order=<o> fwd=<f> ..." -> the choice a record names (false: no record / not readable)
 bool parse_plan_record(const std::string& note, dnas::PlanChoice* choice) {
-  int o = -1, f = -1;
-  if (sscanf(note.c_str(), "order=%d fwd=%d", &o, &f) != 2 || o < 0 || o > 2 || f < 0 || f > 1) return false;
+  int o = -1, f = -1, sl = 0;
+  if (sscanf(note.c_str(), "order=%d fwd=%d slack=%d", &o, &f, &sl) < 2 || o < 0 || o > 2 || f < 0 || f > 1 || sl < 0 || sl > 8) return false;
   choice->order = o;
   choice->forwardedRows = f;
+  choice->slack = sl;
   return true;
 }
 
@@ -234,7 +235,7 @@ bool parse_plan_record(const std::string& note, dnas::PlanChoice* choice) {
 // and timed on synthetic reads (one work-group each), and the verdict is kept next to the cached code objects
 // (kcache/tune_<hash>.txt; dnastore_amd/tune/ ships the verdicts of the fixture and bench machines).
 int tune_row_program(const dnas_flat_model* fm, int device_id, int threads, dnas::PlanChoice* choice) {
-  *choice = dnas::PlanChoice{0, 1};
+  *choice = dnas::PlanChoice{0, 1, 0};
   const std::string name = tune_record_name(fm, 1, threads);
   if (parse_plan_record(dnas::cacheNoteRead(name), choice)) return DNAS_OK;
   // 240 reads of 480 bases of the kind the machine is for: what a random walk through the machine emits (a code word
@@ -274,7 +275,7 @@ int tune_row_program(const dnas_flat_model* fm, int device_id, int threads, dnas
   std::vector<double> ll(nReads);
   std::vector<uint8_t> st(nReads);
   // the default first: another candidate has to beat it by 1.5 % (run-to-run differences of one program stay below 0.5 %)
-  const dnas::PlanChoice candidates[] = {{0, 1}, {0, 2}, {1, 1}};
+  const dnas::PlanChoice candidates[] = {{0, 1, 0}, {0, 2, 0}, {0, 2, 8}, {1, 1, 0}};
   double best = 0;
   std::string report;
   for (const dnas::PlanChoice& c : candidates) {
@@ -284,7 +285,7 @@ int tune_row_program(const dnas_flat_model* fm, int device_id, int threads, dnas
     }
     dnas_model* t = nullptr;
     const std::string options = "tier=A,autotune=0,plan_order=" + std::to_string(c.order) + ",plan_fwd=" + std::to_string(c.forwardedRows) +
-                                ",threads=" + std::to_string(threads);
+                                ",plan_slack=" + std::to_string(c.slack) + ",threads=" + std::to_string(threads);
     int rc = dnas_model_create_ex(fm, device_id, (size_t)64 << 30, options.c_str(), &t);
     if (rc != DNAS_OK) { if (c.order == 1 && !c.forwardedRows) return DNAS_OK; continue; }   // (the creation that asked reports what is wrong)
     dnas_batch_stats s{};
@@ -298,13 +299,13 @@ int tune_row_program(const dnas_flat_model* fm, int device_id, int threads, dnas
     s.fill_ms = fastest;
     if (rc != DNAS_OK || !(s.fill_ms > 0)) continue;
     char item[96];
-    snprintf(item, sizeof item, "  order=%d fwd=%d: %.3f ms", c.order, c.forwardedRows, s.fill_ms);
+    snprintf(item, sizeof item, "  order=%d fwd=%d slack=%d: %.3f ms", c.order, c.forwardedRows, c.slack, s.fill_ms);
     report += item;
     if (best == 0 || s.fill_ms < 0.985 * best) { if (best == 0 || s.fill_ms < best) best = s.fill_ms; *choice = c; }
   }
   if (best == 0) return DNAS_OK;
   char head[160];
-  snprintf(head, sizeof head, "order=%d fwd=%d   (fill of %d synthetic reads of %d bases;", choice->order, choice->forwardedRows, nReads, L);
+  snprintf(head, sizeof head, "order=%d fwd=%d slack=%d   (fill of %d synthetic reads of %d bases;", choice->order, choice->forwardedRows, choice->slack, nReads, L);
   dnas::cacheNoteWrite(name, std::string(head) + report + ")\n");
   return DNAS_OK;
 }
@@ -404,6 +405,7 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
     if (const char* s = opt("threads")) wantT = atoi(s);
     if (const char* s = opt("plan_fwd")) want_.forwardedRows = atoi(s) != 0;
     if (const char* s = opt("plan_order")) want_.order = std::max(0, std::min(2, atoi(s)));
+    if (const char* s = opt("plan_slack")) want_.slack = std::max(0, std::min(8, atoi(s)));
     if (const char* s = opt("autotune")) autotune = atoi(s) != 0;
     if (want == 'B') {
       m->tierNote = "tier B forced by DNAS_TIER";
@@ -412,7 +414,7 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
       if (want != 'C' && wantG < 2) {
         const int threadsA = wantT ? wantT : dnas::kTierAThreads;
         dnas::PlanChoice choiceA = want_;
-        if (want_.forwardedRows < 0 && want_.order < 0 && autotune) {
+        if (want_.forwardedRows < 0 && want_.order < 0 && want_.slack < 0 && autotune) {
           int rcTune = tune_row_program(fm, device_id, threadsA, &choiceA);
           if (rcTune != DNAS_OK) return bail(rcTune);
           if (hipSetDevice(device_id) != hipSuccess) return bail(dnas::fail(DNAS_E_DEVICE, "hipSetDevice failed"));
