@@ -192,10 +192,11 @@ class FlatModel:
         out["fwd_rows"], out["fwd_tab"] = fwd_rows, fwd_tab[:, :nw.value]
         return out
 
-    def tune_record_name(self, threads=0):
-        """File name of this machine's row-program tuning record (kernel cache / dnastore_amd/tune/)."""
+    def tune_record_name(self, members=1, threads=0):
+        """File name of this machine's row-program tuning record (kernel cache / dnastore_amd/tune/): members = 1 as tier A,
+        0 / >= 2 as tier C with the smallest / that cluster."""
         buf = ctypes.create_string_buffer(64)
-        _l.check(_l.lib().dnas_tune_record_name(self.view, int(threads), buf, 64))
+        _l.check(_l.lib().dnas_tune_record_name(self.view, int(members), int(threads), buf, 64))
         return buf.value.decode()
 
     def precompile_cluster(self, members=0):

@@ -426,10 +426,12 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
         whyNotA = "cluster forced";
       }
       if (!m->plan.ok && want != 'A') {
-        // (clusters are not tuned: on both machines that need them the program with F rows is slower -- 0.175 against 0.185
-        //  on the 46 670-state one, 0.048 against 0.068 on the 258 538-state one -- and planning them twice takes seconds;
-        //  plan_fwd=1 still asks for it)
-        m->plan = dnas::chooseClusterPlan(*fm, wantG, wantT, want_);
+        // (clusters are not timed here -- planning a 258 538-state machine takes seconds per candidate -- but a recorded
+        //  verdict is followed: tools/make_tune_records.py times the dealing orders for the bench machines)
+        dnas::PlanChoice choiceC = want_;
+        if (want_.forwardedRows < 0 && want_.order < 0 && want_.slack < 0 && autotune)
+          (void)parse_plan_record(dnas::cacheNoteRead(tune_record_name(fm, wantG >= 2 ? wantG : 0, wantT)), &choiceC);
+        m->plan = dnas::chooseClusterPlan(*fm, wantG, wantT, choiceC);
         if (!m->plan.ok) m->plan.whyNot = "one work-group: " + whyNotA + "; cluster: " + m->plan.whyNot;
       }
       if (!m->plan.ok) {
@@ -1124,7 +1126,7 @@ extern "C" int dnas_tiera_precompile(const dnas_flat_model* fm, char* note, size
     // the row program a model of this machine will run: as the environment says, else as a recorded verdict says
     // (tune_forwarded_rows), else the plain one
     dnas::PlanChoice choice;
-    if (!getenv("DNAS_PLAN_FWD") && !getenv("DNAS_PLAN_ORDER"))
+    if (!getenv("DNAS_PLAN_FWD") && !getenv("DNAS_PLAN_ORDER") && !getenv("DNAS_PLAN_SLACK"))
       (void)parse_plan_record(dnas::cacheNoteRead(tune_record_name(fm, 1, dnas::kTierAThreads)), &choice);
     const dnas::TierAPlan p = dnas::buildTierAPlan(*fm, dnas::kTierAThreads, choice);
     std::string msg;
@@ -1172,7 +1174,10 @@ extern "C" int dnas_model_read_events(dnas_model* m, int64_t read_index, uint64_
 extern "C" int dnas_tierc_precompile(const dnas_flat_model* fm, int32_t members, char* note, size_t note_cap) {
   if (!fm) return dnas::fail(DNAS_E_INVALID, "null argument");
   try {
-    const dnas::TierAPlan p = dnas::chooseClusterPlan(*fm, members, 0);
+    dnas::PlanChoice choice;      // as a model of this machine will be planned: the environment, else its tuning record
+    if (!getenv("DNAS_PLAN_FWD") && !getenv("DNAS_PLAN_ORDER") && !getenv("DNAS_PLAN_SLACK"))
+      (void)parse_plan_record(dnas::cacheNoteRead(tune_record_name(fm, members >= 2 ? members : 0, 0)), &choice);
+    const dnas::TierAPlan p = dnas::chooseClusterPlan(*fm, members, 0, choice);
     if (!p.ok) return dnas::fail(DNAS_E_UNSUPPORTED, p.whyNot);
     (void)dnas::jitCompile(p.defines, p.key);
     const std::string msg = "tier C: G=" + std::to_string(p.G) + " K=" + std::to_string(p.K) + " inbox rows " + std::to_string(p.nGRows) +
@@ -1223,9 +1228,10 @@ extern "C" int dnas_tierc_plan(const dnas_flat_model* fm, int32_t members, int32
 // Tier C diagnostics of the last call: clusters that ran, and how many of them had members on more than one XCD.
 // The name of the tuning record of a tier-A machine (tune_row_program above; tools/make_tune_records.py writes the records
 // that ship with the library from bench-like reads).
-extern "C" int dnas_tune_record_name(const dnas_flat_model* fm, int32_t threads, char* out, size_t cap) {
+extern "C" int dnas_tune_record_name(const dnas_flat_model* fm, int32_t members, int32_t threads, char* out, size_t cap) {
   if (!fm || !out || cap < 40) return dnas::fail(DNAS_E_INVALID, "dnas_tune_record_name: bad argument");
-  const std::string name = tune_record_name(fm, 1, threads > 0 ? threads : dnas::kTierAThreads);
+  // members 1: tier A (threads 0 = 1024); 0 or >= 2: tier C with the smallest / that cluster (threads 0 = chosen by the planner)
+  const std::string name = tune_record_name(fm, members, members == 1 && threads <= 0 ? dnas::kTierAThreads : threads);
   strncpy(out, name.c_str(), cap - 1);
   out[cap - 1] = 0;
   return DNAS_OK;

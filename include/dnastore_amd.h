@@ -190,9 +190,11 @@ int dnas_tierc_plan(const dnas_flat_model *fm, int32_t members, int32_t *info, i
                     size_t entries_cap, uint32_t *meta, int32_t *member_of, int32_t *lds_index, int32_t *lattice_slot,
                     uint32_t *fold);
 int dnas_model_cluster_census(dnas_model *model, int32_t *clusters, int32_t *split);
-/* The file name of the row-program tuning record of a tier-A machine (threads = 0: 1024): "tune_<hash>.txt", looked for in the
- * kernel cache and in <library dir>/tune/.  A record starts with "order=<0|1|2> fwd=<0|1>" (options plan_order, plan_fwd). */
-int dnas_tune_record_name(const dnas_flat_model *fm, int32_t threads, char *out, size_t cap);
+/* The file name of a machine's row-program tuning record -- members = 1: as tier A (threads = 0: 1024); members = 0 or >= 2: as
+ * tier C with the smallest / that cluster (threads as given to the model, 0 = the planner's choice) --: "tune_<hash>.txt", looked
+ * for in the kernel cache and in <library dir>/tune/.  A record starts with "order=<0|1|2> fwd=<0|1> slack=<0..8>" (options
+ * plan_order, plan_fwd, plan_slack). */
+int dnas_tune_record_name(const dnas_flat_model *fm, int32_t members, int32_t threads, char *out, size_t cap);
 /* Analysis / test aid: the F rows of the plan (members = 1: tier A, else the tier-C plan as dnas_tierc_plan describes it) --
  * rows whose states have one in-edge, from the state in the row above in the same thread, and are evaluated from that
  * thread's registers instead of an LDS accumulator.  fwd_rows[rows][3] = {index among the F rows (0: not one), kind of the

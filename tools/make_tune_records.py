@@ -18,17 +18,25 @@ import bench
 OUT = sys.argv[1]
 os.makedirs(OUT, exist_ok=True)
 G = os.path.join(ROOT, "tests", "golden", "ref_data")
-machines = [(n, da.Machine.fromFile(os.path.join(G, n)), 29) for n in ("l4c4.json", "mr2l4c4.json", "h74l4c4.json", "s16mr2l4c4.json", "s16h74l4c4.json")]
+# (name, machine, payload bytes per read, reads, members: 1 = tier A, 0 = tier C with the smallest cluster)
+machines = [(n, da.Machine.fromFile(os.path.join(G, n)), 29, 2160, 1) for n in ("l4c4.json", "mr2l4c4.json", "h74l4c4.json", "s16mr2l4c4.json", "s16h74l4c4.json")]
 wl = bench.workload(da, 3, "a")
-machines.append(("water64.1*l4c4", wl["machine"], wl["payload_bytes"]))
+machines.append(("water64.1*l4c4", wl["machine"], wl["payload_bytes"], 2160, 1))
+wl = bench.workload(da, 1, "a")
+machines.append(("configs[1], 46 670 states", wl["machine"], wl["payload_bytes"], 64, 0))
+if "--no-4b" not in sys.argv:
+    wl = bench.workload(da, 3, "b")
+    machines.append(("configs[3] as written, 258 538 states", wl["machine"], wl["payload_bytes"], 16, 0))
 params = da.MutatorParams.fromFlags(global_=True)
-for name, m, payload in machines:
-    reads = bench.make_reads(m, 0, 2160, payload_bytes=payload)      # three launches: the traceback of one runs beside the fill of the next, as in a long job
+for name, m, payload, n_reads, members in machines:
+    # tier A: three launches -- the traceback of one runs beside the fill of the next, as in a long job; clusters: one
+    reads = bench.make_reads(m, 0, n_reads, payload_bytes=payload)
     fm = da.FlatModel(m, params)
     results = []
-    for order, fwd, slack in [(1, 0, 0)] + [(2, 0, sl) for sl in range(9)] + [(1, 1, 0)]:
+    candidates = [(1, 0, 0)] + [(2, 0, sl) for sl in (range(9) if members == 1 else (0, 4, 8))] + ([(1, 1, 0)] if members == 1 else [])
+    for order, fwd, slack in candidates:
         try:
-            dec = da.ViterbiDecoder(m, params, options="tier=A,autotune=0,plan_order=%d,plan_fwd=%d,plan_slack=%d" % (order, fwd, slack))
+            dec = da.ViterbiDecoder(m, params, options="tier=%s,autotune=0,plan_order=%d,plan_fwd=%d,plan_slack=%d" % ("A" if members == 1 else "C", order, fwd, slack))
         except da.DnasError as e:
             continue
         ms = []
@@ -41,7 +49,7 @@ for name, m, payload in machines:
     fastest = min(results, key=lambda r: r[3])
     if fastest[3] < 0.985 * best[3]:
         best = fastest
-    text = "order=%d fwd=%d slack=%d   (fill of 2160 bench reads, %s;%s)\n" % (best[0], best[1], best[2], name, "".join("  %d/%d/%d: %.2f ms" % r for r in results))
-    path = os.path.join(OUT, fm.tune_record_name())
+    text = "order=%d fwd=%d slack=%d   (fill of %d bench reads, %s;%s)\n" % (best[0], best[1], best[2], n_reads, name, "".join("  %d/%d/%d: %.2f ms" % r for r in results))
+    path = os.path.join(OUT, fm.tune_record_name(members))
     open(path, "w").write(text)
     print(os.path.basename(path), text.strip(), flush=True)
