@@ -130,9 +130,10 @@ int dnas_model_create(const dnas_flat_model *fm, int device_id, size_t arena_byt
  * fill launch), cluster_timeout_s (tier C watchdog per lattice column), checkpoint = auto | always | never and
  * segment = columns (bounded-memory decode of reads whose lattice -- the reference's ViterbiMatrix::cell,
  * viterbi.h:48-50 -- does not fit the arena: segments of the lattice are filled from checkpoints and traced back one
- * after the other; results are bit-identical), traceback = thread, persistent, arena_fraction, plan_order = 0 | 1 | 2 and plan_fwd = 0 | 1
- * (the row program: states dealt depth first / breadth first / by longest-path level; with rows that are evaluated from the
- * registers of the row above.  Neither given: the machine's tuning record decides -- shipped in <library dir>/tune/, or left in
+ * after the other; results are bit-identical), traceback = thread, persistent, arena_fraction, plan_order = 0 | 1 | 2, plan_slack = 0 .. 8 and
+ * plan_fwd = 0 | 1 (the row program: states dealt depth first / breadth first / by longest-path level, there with that many
+ * eighths of the room between a state's earliest and latest level used; with rows that are evaluated from the registers of
+ * the row above.  None given: the machine's tuning record decides -- shipped in <library dir>/tune/, or left in
  * the kernel cache by the timing run of the first model of an unknown tier-A machine; autotune = 0: the default program).  A key that is absent
  * falls back to the environment variable DNAS_<KEY IN UPPER CASE>. */
 int dnas_model_create_ex(const dnas_flat_model *fm, int device_id, size_t arena_bytes, const char *options,
