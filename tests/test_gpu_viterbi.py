@@ -296,6 +296,25 @@ def test_arena_replanned_when_the_device_has_less_memory_than_at_creation(da, re
     dec.close()
 
 
+@pytest.mark.parametrize("options", ["plan_order=0", "plan_order=2", "plan_order=2,plan_slack=8", "plan_order=2,plan_slack=3,plan_fwd=1"])
+def test_full_lattice_under_every_dealing_order(da, oracle_mod, ref_data, options):
+    """The row program may be dealt depth first, breadth first (the default of every other test) or by longest-path level, with
+    or without F rows (tuning records pick per machine): the cells are the oracle's every time."""
+    O = oracle_mod
+    path = os.path.join(ref_data, "s16h74l4c4.json")
+    flags = dict(global_=True)
+    dec = da.ViterbiDecoder(da.Machine.fromFile(path), da.MutatorParams.fromFlags(**flags), options=options)
+    orc = O.ViterbiOracle(O.Machine.from_file(path), O.MutatorParams.from_cli(**flags))
+    reads = [seq for _, seq in da.read_fastseqs(os.path.join(ref_data, "hello.s16h74.del.fa"))]
+    out, ll, st = dec.decode(reads)
+    for i, r in enumerate(reads):
+        s, oll, olat = orc.decode(r, want_lattice=True)
+        assert out[i] == s and ll[i] == oll
+        lat = np.ascontiguousarray(dec.lattice(i, len(r)).transpose(0, 2, 1))
+        assert np.array_equal(lat.view(np.uint64), olat.view(np.uint64))
+    dec.close()
+
+
 def test_row_program_autotune(da, oracle_mod, ref_data, tmp_path, monkeypatch):
     """autotune=1 (the library's default; the suite runs with DNAS_AUTOTUNE=0): the first model of a machine times the row
     program with and without F rows on a synthetic read, keeps the verdict in the kernel cache, and later models read it;

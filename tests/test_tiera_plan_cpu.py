@@ -216,6 +216,26 @@ def test_plan_with_forwarded_rows(oracle_mod, ref_data, monkeypatch):
             assert np.array_equal(D_lat.view(np.uint64), np.ascontiguousarray(olat[:, :, 1]).view(np.uint64))
 
 
+@pytest.mark.parametrize("order,slack", [(0, 0), (2, 0), (2, 8), (2, 3)])
+def test_plan_dealing_orders(oracle_mod, ref_data, monkeypatch, order, slack):
+    """The other dealing orders (DNAS_PLAN_ORDER: 0 depth first, 2 longest-path levels with DNAS_PLAN_SLACK eighths of the room
+    used; 1, breadth first, is the default every other test runs): same edges, same lattice, for tier A and a cluster of two."""
+    import dnastore_amd as da
+    O = oracle_mod
+    monkeypatch.setenv("DNAS_PLAN_ORDER", str(order))
+    monkeypatch.setenv("DNAS_PLAN_SLACK", str(slack))
+    path = os.path.join(ref_data, "mr2l4c4.json")
+    flags = dict(global_=True)
+    fm = da.FlatModel(da.Machine.fromFile(path), da.MutatorParams.fromFlags(**flags))
+    read = da.read_fastseqs(os.path.join(ref_data, "hello.mr2.fa"))[0][1][:20]
+    orc = O.ViterbiOracle(O.Machine.from_file(path), O.MutatorParams.from_cli(**flags))
+    _, _, olat = orc.decode(read, want_lattice=True)
+    for members in (1, 2):
+        S_lat, D_lat = _emulate(fm, da.tokenize(read), local=False, members=members)
+        assert np.array_equal(S_lat.view(np.uint64), np.ascontiguousarray(olat[:, :, 0]).view(np.uint64))
+        assert np.array_equal(D_lat.view(np.uint64), np.ascontiguousarray(olat[:, :, 1]).view(np.uint64))
+
+
 def test_plan_row_program_invariants(ref_data):
     """Every state placed once, rows within capacity, null edges only into rows with an S stripe."""
     import dnastore_amd as da
