@@ -93,6 +93,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 #ifndef DNAS_ENT_ONDEMAND
 #define DNAS_ENT_ONDEMAND 0
 #endif
+#ifndef DNAS_EARLY_OFFERS
+#define DNAS_EARLY_OFFERS 1   // one work-group per read: a column's emit offers are made inside phase C of the column before
+#endif
 
 // kernel-argument block (mirrors runtime.hip TierAArgs)
 struct TierAArgs {
@@ -189,6 +192,7 @@ constexpr double kFresh = __builtin_huge_val();   // "not evaluated in this colu
 // reduction.  Sync block of one cluster (64 u32): [0] GE, [1] abort,
 // [2, 2+G) idle word per member, [40] placement census (OR of 1 << XCC id).
 constexpr int G_ = DNAS_G;
+constexpr bool kEarlyOffers = DNAS_EARLY_OFFERS != 0 && DNAS_G == 1;
 constexpr unsigned kCells = (unsigned)DNAS_G * DNAS_GROWS * DNAS_T;
 constexpr unsigned kXStride = 3u * kCells + 8u;   // doubles per cluster
 
@@ -413,6 +417,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
   const int c1 = L;
 #endif
 
+  bool earlyOffered = false;     // the offers of the column about to start have been made already (phase C of the column before)
   for (int pos = c0; pos <= c1 && !aborted; ++pos) {
     double* const col = latM + (size_t)pos * lanes * NS;
     const int x = pos > 0 ? seq[pos - 1] : 0;
@@ -427,8 +432,8 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
     // DC (all -inf since phase C); after the barrier each state takes what it was offered,
     // folds in the T1 lane (handed over in the D registers by phase C) and clears the cell for
     // the D offers of the fixpoint.
-    if (pos > 0) {
-      const unsigned subRow = (unsigned)kTabBase + 32u + (unsigned)x * 8u;   // &sub[0][x]
+    auto emitOffers = [&](int xCol) {
+      const unsigned subRow = (unsigned)kTabBase + 32u + (unsigned)xCol * 8u;   // &sub[0][x]
       static_for<0, K>([&](auto kc) {
         constexpr int k = kc.value, o = rowOffset(k);
         if (rowLive(k) && S[k] > kNegInf) {
@@ -448,13 +453,17 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
           });
         }
       });
-    }
+    };
+    // (one work-group per read: the offers of this column were made inside phase C of the column before, while its first
+    //  history loads were in flight, and the barrier that ends phase C has seen them land -- see there)
+    const bool offersMade = kEarlyOffers && earlyOffered;
+    if (pos > 0 && !offersMade) emitOffers(x);
     if constexpr (G_ > 1) {
       STAMP(tA)
       clusterBarrier();            // every member's offers of the previous column have landed
       STAMP(tX)
       if (aborted) break;
-    } else if (pos > 0) {
+    } else if (pos > 0 && !offersMade) {
       __syncthreads();             // every offer of the previous column has landed
     }
     STAMP(tA)
@@ -766,6 +775,19 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
         });
       }
       const int xn = pos < L ? seq[pos] : 0;
+      if constexpr (kEarlyOffers) {
+        // every accumulator is cleared NOW (not row by row below), so that the offers of the next column can go out while
+        // the history of the first row group is on its way
+        static_for<0, K>([&](auto kc) {
+          constexpr int k = kc.value;
+          if constexpr (rowLive(k)) {
+            if constexpr (kRows[k].fwd == 0) ldsWrite(ldsB, DC_OWN(k), kNegInf);
+            if constexpr (kRows[k].sIdx >= 0) ldsWrite(ldsB, SC_OWN(k), kNegInf);
+          }
+        });
+        __syncthreads();
+        earlyOffered = pos < c1;
+      }
       int xh[D_ > 0 ? D_ : 1];   // xh[i] = x_{pos-i}
       static_for<0, D_>([&](auto ic) { xh[ic.value] = pos - ic.value >= 1 ? seq[pos - ic.value - 1] : 0; });
       // rows 2m, 2m+1 of a thread are neighbours in the lattice: 16-byte loads and stores
@@ -794,13 +816,18 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
             });
           }
         });
+        if constexpr (kEarlyOffers && gc.value == 0) {
+          if (earlyOffered) emitOffers(xn);       // column pos + 1: ((S(pos) + score) + noGap) + sub[base][x_{pos+1}]
+        }
         static_for<k0, k1>([&](auto kc) {
           constexpr int k = kc.value;
           if constexpr (!rowLive(k)) { Dv[k] = kNegInf; return; }
           const double s = S[k];
           const int mdl = (int)(metaG[k - k0] & 15u);
-          if constexpr (kRows[k].fwd == 0) ldsWrite(ldsB, DC_OWN(k), kNegInf);
-          if constexpr (kRows[k].sIdx >= 0) ldsWrite(ldsB, SC_OWN(k), kNegInf);
+          if constexpr (!kEarlyOffers) {
+            if constexpr (kRows[k].fwd == 0) ldsWrite(ldsB, DC_OWN(k), kNegInf);
+            if constexpr (kRows[k].sIdx >= 0) ldsWrite(ldsB, SC_OWN(k), kNegInf);
+          }
           // T1(pos): chain from the deepest element (i = D-1) to i = 0.  Nearly every state has a
           // full context (mdl == D) and nearly every column a full history: that case is straight
           // line code, chosen per wave.
