@@ -183,13 +183,6 @@ class FlatModel:
                                           member_of.ctypes.data, lds.ctypes.data, lat.ctypes.data, fold.ctypes.data))
         out = dict(G=G, K=K, T=T, n_entries=ne, n_s_rows=int(info[4]), n_inbox_rows=int(info[5]), shapes=shapes, entries=ent, meta=meta,
                    member_of=member_of, lds_index=lds, lattice_slot=lat, fold=fold[:, :int(info[5])])
-        # the F rows of the plan: fwd_rows int32[K][3], fwd_tab uint32[G][words][T] (include/dnastore_amd.h)
-        nw = ctypes.c_int32()
-        _l.check(_l.lib().dnas_tiera_plan_forwarded(self.view, G, None, None, 0, ctypes.addressof(nw)))
-        fwd_rows = np.zeros((K, 3), dtype=np.int32)
-        fwd_tab = np.zeros((G, max(nw.value, 1), T), dtype=np.uint32)
-        _l.check(_l.lib().dnas_tiera_plan_forwarded(self.view, G, fwd_rows.ctypes.data, fwd_tab.ctypes.data, fwd_tab.size, ctypes.addressof(nw)))
-        out["fwd_rows"], out["fwd_tab"] = fwd_rows, fwd_tab[:, :nw.value]
         return out
 
     def tune_record_name(self, members=1, threads=0):
@@ -197,6 +190,13 @@ class FlatModel:
         0 / >= 2 as tier C with the smallest / that cluster."""
         buf = ctypes.create_string_buffer(64)
         _l.check(_l.lib().dnas_tune_record_name(self.view, int(members), int(threads), buf, 64))
+        return buf.value.decode()
+
+    @staticmethod
+    def kernel_source_hash():
+        """Hash of the fill kernel's source inside the library (what tuning records name as kernel=)."""
+        buf = ctypes.create_string_buffer(32)
+        _l.check(_l.lib().dnas_kernel_source_hash(buf, 32))
         return buf.value.decode()
 
     def precompile_cluster(self, members=0):

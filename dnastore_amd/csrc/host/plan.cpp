@@ -5,7 +5,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <functional>
 #include <map>
 #include <numeric>
 #include <sstream>
@@ -91,8 +90,7 @@ void depthFirstWalk(int N, const std::vector<Edge>& edges, const std::vector<std
 // of the wave whose half does not yet use that bank pair, then the same residue elsewhere.
 // Returns the lane of every state; rowMembers[(member * K + row)] lists the states of each row.
 std::vector<int> placeLanes(int N, int G, int K, int T, const std::vector<Edge>& edges, const std::vector<std::vector<int>>& inOf,
-                            const std::vector<int>& part, const std::vector<int>& rowOfState, const std::vector<int>& segOfRow,
-                            const std::vector<int>& attOf, std::vector<std::vector<int>>* rowMembersOut) {
+                            const std::vector<int>& part, const std::vector<int>& rowOfState, std::vector<std::vector<int>>* rowMembersOut) {
   std::vector<int> laneOf(N, -1);
   std::vector<std::vector<int>>& rowMembers = *rowMembersOut;
   rowMembers.assign((size_t)G * K, {});
@@ -113,10 +111,6 @@ std::vector<int> placeLanes(int N, int G, int K, int T, const std::vector<Edge>&
       const std::vector<int>& mem = rowMembers[b];
       if (mem.empty()) continue;          // padding row
       const int n = (int)mem.size();
-      if (segOfRow[(int)(b % (size_t)K)] == 0) {          // an F row: every state sits in the lane of the state it hangs under
-        for (int j : mem) laneOf[j] = laneOf[attOf[j]];
-        continue;
-      }
       std::vector<char> lanesFree(T, 1);
       std::vector<int> newLane(n, -1), lead(n, -1);
       std::vector<std::array<unsigned char, 32>> bankUse(T / 32);   // per 32-lane half: leads per bank pair
@@ -157,16 +151,11 @@ std::vector<int> placeLanes(int N, int G, int K, int T, const std::vector<Edge>&
 }
 
 TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const PlanChoice& choice = PlanChoice()) {
-  const int forwardedRows = choice.forwardedRows;
   TierAPlan p;
   const int N = fm.n_states, D = fm.max_dup_len;
   if (T != 1024 && T != 512) { TierAPlan bad; bad.whyNot = "work-groups of 512 or 1024 threads"; return bad; }
   // a work-group fills a CU either way: 16 waves of 128 registers, or 8 waves of 256 with twice the rows per thread
   const int maxRows = kTierAMaxRows * 1024 / T, maxEntries = kMaxEntries * 1024 / T;
-  // Pair sweeps (the accumulators of rows 2m and 2m+1 read together): +3 % on the 46 670-state machine, -25 % on the
-  // 258 538-state one -- off unless asked for (DNAS_PAIR_SWEEP=1).
-  bool pairSweep = false;
-  if (const char* e = getenv("DNAS_PAIR_SWEEP")) pairSweep = atoi(e) != 0;
   p.N = N; p.D = D; p.T = T; p.G = G;
   auto no = [&](const std::string& why) { p.ok = false; p.whyNot = why; return p; };
   if (D > 8) return no("more than 8 duplication lanes");
@@ -344,36 +333,6 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const P
     walk.clear();
     for (int g = 0; g < G; ++g) walk.insert(walk.end(), walkOf[g].begin(), walkOf[g].end());
   }
-  // ---- forwarded runs (forwardedRows / DNAS_PLAN_FWD; in a cluster: inside a member).  A state whose ONLY in-edge comes
-  // from the state in the row right above it, in the same thread, needs no LDS accumulator, no read and no idle check: its
-  // cells are a function of that thread's registers ("F rows" of the program; the kernel evaluates them from S and D of
-  // the row above).  Candidates: the first such child of every state along the depth-first walk, in runs of at most maxRun
-  // states; the dealing below decides which of them really end up under their parent (a run needs a segment of the
-  // program long enough).  Measured on s16h74l4c4 (7 of 14 rows become F rows, 5 700 states sit under their parent): bit
-  // exact, but 0.44 of the roofline against 0.53 -- the heads are left with 7 rows to run down (18.7 sweeps per column
-  // instead of 14.4) and a sweep costs the same (3.5 k cycles against 3.3 k): it is bound by the rows that grow, not by the
-  // LDS round trips of the rows that do not.  On water64.1*l4c4 (long unbranched runs) the same program is 6.6 % faster.
-  // Which one a machine gets is therefore measured, not guessed: the runtime times both on a synthetic read when a
-  // model is first created for the machine (runtime.hip, option autotune).
-  int maxRun = 3;
-  if (const char* e = getenv("DNAS_PLAN_RUN")) maxRun = std::max(1, std::min(4, atoi(e)));
-  bool useFwd = forwardedRows > 0;
-  if (forwardedRows < 0)
-    if (const char* e = getenv("DNAS_PLAN_FWD")) useFwd = atoi(e) != 0;
-  if (useFwd) pairSweep = false;          // (the pair sweep reads accumulators that F rows do not have)
-  if (!useFwd) maxRun = 1;
-  std::vector<int> candChild(N, -1), candParent(N, -1), candEdge(N, -1), runDepth(N, 0);
-  if (maxRun > 1)
-    for (int u : walk) {
-      if (runDepth[u] + 1 >= maxRun) continue;
-      for (int e : outOf[u]) {
-        const int c = edges[e].dst;
-        if (c == u || c == 0 || inOf[c].size() != 1 || parent[c] != u || candParent[c] >= 0) continue;
-        candChild[u] = c; candParent[c] = u; candEdge[c] = e; runDepth[c] = runDepth[u] + 1;
-        break;
-      }
-    }
-
   int nInboxRows = 0;
   for (int g = 0; g < G; ++g) nInboxRows = std::max(nInboxRows, (inboxCount[g] + T - 1) / T);
   if (G > 1 && nInboxRows == 0) nInboxRows = 1;   // (a cluster whose members never talk: keep the kernel's shape)
@@ -450,14 +409,12 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const P
     if (it == typeId.end()) { it = typeId.emplace(type[j], (int)types.size()).first; types.push_back(type[j]); }
     typeOf[j] = it->second;
   }
-  // deal the states of every member onto a program (caps per row) along the depth-first walk
-  // deal the states onto a program (caps per row; segLen[k]: the rows of the segment that J row k heads -- itself and the
-  // F rows below it --, 0 for an F row) along the depth-first walk.  att[c]: the state c really sits under (-1: none).
-  auto deal = [&](const std::vector<Type>& caps, const std::vector<int>& segLen, std::vector<int>* rows, std::vector<int>* att) -> bool {
+  // deal the states of every member onto a program (caps per row) along the walk
+  auto deal = [&](const std::vector<Type>& caps, std::vector<int>* rows) -> bool {
     std::vector<unsigned> admits(types.size(), 0), own(types.size(), 0);
     for (size_t t = 0; t < types.size(); ++t)
       for (int k = 0; k < K; ++k)
-        if (segLen[k] >= 1 && types[t][0] <= caps[k][0] && types[t][1] <= caps[k][1] && types[t][2] <= caps[k][2] && ((caps[k][3] >> types[t][3]) & 1) &&
+        if (types[t][0] <= caps[k][0] && types[t][1] <= caps[k][1] && types[t][2] <= caps[k][2] && ((caps[k][3] >> types[t][3]) & 1) &&
             (types[t][4] == 0 || caps[k][4] >= 1)) {
           // caps[k][4]: 0 no state that offers into another member, 1 any state, 2 a row reserved for such states
           admits[t] |= 1u << k;
@@ -465,15 +422,7 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const P
           const bool reserved = caps[k][4] == 2;
           if (reserved ? types[t][4] == 1 : types[t][1] == caps[k][1]) own[t] |= 1u << k;
         }
-    unsigned segAtLeast[6] = {0, 0, 0, 0, 0, 0}, segExactly[6] = {0, 0, 0, 0, 0, 0};
-    for (int k = 0; k < K; ++k)
-      for (int L = 1; L <= 5; ++L) {
-        if (segLen[k] >= L) segAtLeast[L] |= 1u << k;
-        if (segLen[k] == L) segExactly[L] |= 1u << k;
-      }
     rows->assign(N, -1);
-    att->assign(N, -1);
-    std::vector<char> hasUnder(N, 0);      // a state sits under this one
     for (int g = 0; g < G; ++g) {
       std::vector<std::vector<int>> members(K);
       unsigned freeRows = (1u << K) - 1u;
@@ -482,14 +431,11 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const P
         members[k].push_back(j);
         if ((int)members[k].size() == T) freeRows &= ~(1u << k);
       };
-      auto pick = [&](int j, unsigned exclude, int need) -> int {
+      auto pick = [&](int j, unsigned exclude) -> int {
         const int par = parent[j];
-        // (pair sweeps: the kernel reads the accumulators of rows 2m and 2m+1 together, so a chain runs along rows of
-        //  one parity)
-        const int start = (par >= 0 && (*rows)[par] >= 0) ? (*rows)[par] + (pairSweep ? 2 : 1) : 0;
+        const int start = (par >= 0 && (*rows)[par] >= 0) ? (*rows)[par] + 1 : 0;
         const unsigned base = freeRows & ~exclude;
-        const unsigned sets[4] = {own[typeOf[j]] & segExactly[need], own[typeOf[j]] & segAtLeast[need], admits[typeOf[j]] & segExactly[need],
-                                  admits[typeOf[j]] & segAtLeast[need]};
+        const unsigned sets[2] = {own[typeOf[j]], admits[typeOf[j]]};
         for (unsigned set : sets) {
           const unsigned avail = set & base;
           if (!avail) continue;
@@ -499,59 +445,40 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const P
         return -1;
       };
       for (int j : walkOf[g]) {
-        if ((*rows)[j] >= 0) continue;          // sits under its parent already
-        int run[5], L = 1;
-        run[0] = j;
-        for (int c = candChild[j]; c >= 0 && L < maxRun; c = candChild[c]) run[L++] = c;
-        int k = -1;
-        for (; L >= 1; --L) {
-          k = pick(j, 0u, L);
-          if (k >= 0) break;
-        }
+        int k = pick(j, 0u);
         if (k < 0) {
-          L = 1;
           // every row that admits j is full: move a more flexible resident of one of them elsewhere
           bool moved = false;
           for (int r = 0; r < K && !moved; ++r) {
             if (!(admits[typeOf[j]] >> r & 1u)) continue;
             for (size_t m = 0; m < members[r].size(); ++m) {
               const int i = members[r][m];
-              if (hasUnder[i] || (*att)[i] >= 0) continue;          // (runs stay where they are)
               if (!(admits[typeOf[i]] & freeRows & ~(1u << r))) continue;
               members[r].erase(members[r].begin() + (long)m);
               freeRows |= 1u << r;
               (*rows)[i] = -1;
-              put(i, pick(i, 1u << r, 1));
+              put(i, pick(i, 1u << r));
               moved = true;
               break;
             }
           }
           if (!moved) return false;
-          k = pick(j, 0u, 1);
+          k = pick(j, 0u);
           if (k < 0) return false;
         }
         put(j, k);
-        for (int i = 1; i < L; ++i) {
-          (*rows)[run[i]] = k + i;
-          members[k + i].push_back(run[i]);
-          (*att)[run[i]] = run[i - 1];
-          hasUnder[run[i - 1]] = 1;
-        }
       }
     }
     return true;
   };
-  auto score = [&](const std::vector<int>& rows, const std::vector<int>& att, int* readsOut, int* backOut, int* entriesOut) -> double {
-    std::vector<char> under(N, 0);
-    for (int j = 0; j < N; ++j) if (att[j] >= 0) under[att[j]] = 1;
+  auto score = [&](const std::vector<int>& rows, int* readsOut, int* backOut, int* entriesOut) -> double {
     std::vector<Type> shape(K, Type{0, 0, 0, 0, 0});
-    std::vector<char> inUse(K, 0), isFRow(K, 0);
+    std::vector<char> inUse(K, 0);
     for (int j = 0; j < N; ++j) {
       const int k = rows[j];
       inUse[k] = 1;
-      if (att[j] >= 0) isFRow[k] = 1;
-      shape[k][0] = std::max(shape[k][0], type[j][0] - (under[j] ? 1 : 0));
-      if (att[j] < 0) shape[k][1] = std::max(shape[k][1], type[j][1]);
+      shape[k][0] = std::max(shape[k][0], type[j][0]);
+      shape[k][1] = std::max(shape[k][1], type[j][1]);
       shape[k][2] = std::max(shape[k][2], type[j][2]);
     }
     int reads = 0, entries = 0;
@@ -561,7 +488,7 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const P
         int clsMask = 0;
         for (int j = 0; j < N; ++j) if (rows[j] == k && type[j][3] != 7) clsMask |= 1 << type[j][3];
         const bool oneClass = clsMask != 0 && (clsMask & (clsMask - 1)) == 0 && clsMask < 16;
-        if (!isFRow[k]) reads += 1 + shape[k][1];
+        reads += 1 + shape[k][1];
         entries += shape[k][0];
         offerCost += !shape[k][2] ? 0.25 * shape[k][0] : (oneClass ? 0.55 * shape[k][0] : shape[k][0]);
       }
@@ -584,7 +511,7 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const P
   };
   auto ldsNeed = [&](int nS) { return (size_t)(p.NSm + nS * T + 8 + 28 + T / 64 + (T / 64 + 2) / 2 + 1 + 2) * sizeof(double); };
 
-  std::vector<int> rowOfState, attOf(N, -1), segOfRow(K, 1);
+  std::vector<int> rowOfState;
   std::vector<Type> bestCaps;
   double bestScore = -1;
   std::string why = "no row program fits";
@@ -612,23 +539,19 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const P
   }
   long biggest = 0;
   for (int g = 0; g < G; ++g) biggest = std::max(biggest, (long)walkOf[g].size());
-  // Candidate programs over one segment structure (segLen per row).  The S rows, plain rows, quantile caps ... are laid
-  // out over the J rows only ("virtual" rows v = 0 .. VK-1).
-  auto tryPrograms = [&](const std::vector<int>& segLen, int minS) {
-    std::vector<int> jRow;
-    for (int k = 0; k < K; ++k) if (segLen[k] >= 1) jRow.push_back(k);
-    const int VK = (int)jRow.size();
-    const bool hasF = VK < K;
+  // Candidate programs: S rows, plain rows, quantile caps ...
+  auto tryPrograms = [&](int minS) {
+    const int VK = K;
     int nRemoteRowsNow = nRemoteRows, nRemoteSRowsNow = nRemoteSRows;
     // K is even (lattice pairs); when the states fit K-1 rows the last one may stay empty and
     // costs nothing in a sweep -- tried both ways
     // (when the rows reserved for the states that offer into other members leave no program -- tiny machines cut into
     //  clusters -- every row may hold them instead)
     for (int attempt = 0; attempt < 2 && bestScore < 0; ++attempt, nRemoteRowsNow = nRemoteSRowsNow = 0)
-    for (int KU = VK; KU >= std::max(1, VK - (hasF ? 0 : 1)); --KU)
+    for (int KU = VK; KU >= std::max(1, VK - 1); --KU)
     for (int nS = minS; nS <= std::min(KU, minS + 2); ++nS) {
       if (ldsNeed(nS + nRemoteSRowsNow) > kTierALdsLimit) { why = "LDS working set " + std::to_string(ldsNeed(nS + nRemoteSRowsNow)) + " B exceeds one CU"; continue; }
-      if (!hasF && (long)KU * T < biggest) continue;
+      if ((long)KU * T < biggest) continue;
       if (nS + nRemoteRowsNow > KU) continue;
       const int KUL = KU - nRemoteRowsNow;                 // rows in front of them
       for (int groups = 1; groups <= std::max(1, std::min(3, nS)); ++groups) {
@@ -682,23 +605,19 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const P
               for (long r = 0; r < need && next < sRows.size(); ++r) vcaps[sRows[next++]][3] = (1 << c) | (1 << 7);
             }
           }
-          std::vector<Type> caps(K, Type{-1, -1, -1, 0, -1});     // F rows: closed to the dealing of heads
-          for (int v = 0; v < VK; ++v) caps[jRow[v]] = vcaps[v];
-          std::vector<int> rows, att;
-          if (!deal(caps, segLen, &rows, &att)) {
+          const std::vector<Type>& caps = vcaps;
+          std::vector<int> rows;
+          if (!deal(caps, &rows)) {
             if (getenv("DNAS_PLAN_DEBUG"))
-              fprintf(stderr, "plan candidate: rows %d (F rows %d) S-rows %d groups %d ascending %d plain %d typedS %d -> states do not fit\n", KU, K - VK, nS, groups,
+              fprintf(stderr, "plan candidate: rows %d S-rows %d groups %d ascending %d plain %d typedS %d -> states do not fit\n", KU, nS, groups,
                       ascending, plainRows, typedS);
             continue;
           }
           int reads = 0, back = 0, entries = 0;
-          const double sc = score(rows, att, &reads, &back, &entries);
-          if (getenv("DNAS_PLAN_DEBUG")) {
-            long nAtt = 0;
-            for (int v : att) nAtt += v >= 0;
-            fprintf(stderr, "plan candidate: rows %d (F rows %d, %ld states under their parent) S-rows %d groups %d ascending %d plain %d typedS %d -> reads %d entries %d back %d score %.0f\n", KU, K - VK, nAtt, nS,
+          const double sc = score(rows, &reads, &back, &entries);
+          if (getenv("DNAS_PLAN_DEBUG"))
+            fprintf(stderr, "plan candidate: rows %d S-rows %d groups %d ascending %d plain %d typedS %d -> reads %d entries %d back %d score %.0f\n", KU, nS,
                     groups, ascending, plainRows, typedS, reads, entries, back, sc);
-          }
           if (const char* pick = getenv("DNAS_PLAN_PICK")) {   // experiments: "rows,S-rows,groups,ascending"
             int a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
             if (sscanf(pick, "%d,%d,%d,%d,%d,%d", &a0, &a1, &a2, &a3, &a4, &a5) == 6 &&
@@ -706,7 +625,7 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const P
           }
           if (entries > maxEntries) { why = "row shapes need " + std::to_string(entries) + " entry registers per thread"; continue; }
           if (bestScore < 0 || sc < bestScore) {
-            bestScore = sc; rowOfState = rows; bestCaps = caps; attOf = att; segOfRow = segLen;
+            bestScore = sc; rowOfState = rows; bestCaps = caps;
             p.sweepReads = reads; p.backEdgesOnWalk = back;
           }
         }
@@ -715,81 +634,13 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const P
   };
   {
     const int minS = (nNullDestMax + T - 1) / T;
-    // ---- with F rows: the segment structure from the census of candidate runs
-    if (maxRun > 1) {
-      // (of the member with the most runs of each length: the members share the program)
-      std::vector<long> nRun(maxRun + 1, 0);
-      {
-        std::vector<std::vector<long>> per(G, std::vector<long>(maxRun + 1, 0));
-        for (int j = 0; j < N; ++j)
-          if (candParent[j] < 0) {
-            int L = 1;
-            for (int c = candChild[j]; c >= 0; c = candChild[c]) ++L;
-            ++per[part[j]][L];
-          }
-        for (int g = 0; g < G; ++g)
-          for (int L = 1; L <= maxRun; ++L) nRun[L] = std::max(nRun[L], per[g][L]);
-      }
-      // segments of L rows, L = maxRun .. 2, then lone rows: runs that find no segment of their length are cut
-      long bestFwd = -1;
-      std::vector<int> bestSegs;
-      const long cap = (long)T * 96 / 100;
-      std::vector<int> segs(maxRun + 1, 0);
-      std::function<void(int, int)> search = [&](int L, int rowsLeft) {
-        if (L == 1) {
-          segs[1] = rowsLeft;
-          std::vector<long> n(nRun);
-          long room = 0, fwd = 0, heads = 0, slots = 0;
-          for (int q = maxRun; q >= 2; --q) {
-            room += (long)segs[q] * cap;
-            const long placed = std::min(n[q], room);
-            room -= placed; fwd += placed * (q - 1); heads += placed;
-            n[q - 1] += n[q] - placed; n[1] += n[q] - placed;     // the rest is cut into q-1 and 1
-            slots += (long)segs[q];
-          }
-          heads += n[1];
-          slots += segs[1];
-          if (heads > slots * cap) return;
-          if (fwd > bestFwd) { bestFwd = fwd; bestSegs = segs; }
-          return;
-        }
-        for (int c = 0; c * L <= rowsLeft; ++c) { segs[L] = c; search(L - 1, rowsLeft - c * L); }
-      };
-      search(maxRun, K);
-      if (bestFwd > 0) {
-        // long segments first: a run's head follows its depth-first parent down the rows
-        std::vector<int> segLen(K, 0);
-        int k = 0;
-        for (int L = maxRun; L >= 1; --L)
-          for (int c = 0; c < bestSegs[L]; ++c) { segLen[k] = L; k += L; }
-        long nUnder = 0;
-        for (int j = 0; j < N; ++j) nUnder += candParent[j] >= 0 && type[j][1];
-        nUnder /= G;
-        // states with null in-edges that end up under their parent need no S cell: fewer S rows may do
-        const int minSF = std::max(0, (int)((nNullDestMax - std::min(nUnder, bestFwd) * 7 / 10 + T - 1) / T));
-        if (getenv("DNAS_PLAN_DEBUG")) {
-          fprintf(stderr, "plan: runs of 1..%d:", maxRun);
-          for (int L = 1; L <= maxRun; ++L) fprintf(stderr, " %ld", nRun[L]);
-          fprintf(stderr, "; segments");
-          for (int L = maxRun; L >= 1; --L) fprintf(stderr, " %dx%d", bestSegs[L], L);
-          fprintf(stderr, "; up to %ld states under their parent; S rows from %d\n", bestFwd, minSF);
-        }
-        tryPrograms(segLen, minSF);
-      }
-    }
-    if (bestScore < 0) tryPrograms(std::vector<int>(K, 1), minS);
+    tryPrograms(minS);
     if (bestScore < 0) return no(why);
   }
 
   // A handful of odd states can spoil what the entries of a row have in common (its score class, emit /
   // null kind): move such minorities (at most 2 % of a row) to a row that admits them and is mixed anyway.
-  std::vector<char> hasUnder(N, 0);       // a state really sits under this one (its edge to it is no entry)
-  for (int j = 0; j < N; ++j) if (attOf[j] >= 0) hasUnder[attOf[j]] = 1;
-  // the out-edges that become entries: all but the one to the state underneath
-  std::vector<std::vector<int>> entOut(N);
-  for (int j = 0; j < N; ++j)
-    for (int e : outOf[j])
-      if (!(attOf[edges[e].dst] == j && candEdge[edges[e].dst] == e)) entOut[j].push_back(e);
+  const std::vector<std::vector<int>>& entOut = outOf;       // every out-edge becomes an entry
   {
     auto clsOf = [&](int j) { int c = -2; for (int e : entOut[j]) c = c == -2 ? edges[e].sc : (c == edges[e].sc ? c : -1); return c; };
     auto kindOf = [&](int j) { int k = -1; for (int e : entOut[j]) { const int q = edges[e].isNull ? 2 : 1; k = k < 0 ? q : (k == q ? q : 0); } return k; };
@@ -815,8 +666,8 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const P
       for (int k = 0; k < K; ++k) {
         std::map<int, std::vector<int>> byVal;
         for (int j = 0; j < N; ++j)
-          if (rowOfState[j] == k && !entOut[j].empty() && attOf[j] < 0 && !hasUnder[j]) byVal[attr == 0 ? clsOf(j) : kindOf(j)].push_back(j);
-        if (byVal.size() < 2 || segOfRow[k] != 1) continue;     // (rows of runs stay as dealt)
+          if (rowOfState[j] == k && !entOut[j].empty()) byVal[attr == 0 ? clsOf(j) : kindOf(j)].push_back(j);
+        if (byVal.size() < 2) continue;
         size_t most = 0, total = 0;
         for (const auto& kv : byVal) { most = std::max(most, kv.second.size()); total += kv.second.size(); }
         if (total - most > (size_t)G * T / 50) continue;
@@ -824,7 +675,7 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const P
           if (kv.second.size() == most) continue;
           for (int j : kv.second) {
             for (int k2 = 0; k2 < K; ++k2) {
-              if (k2 == k || segOfRow[k2] != 1 || fill[(size_t)part[j] * K + k2] >= T) continue;
+              if (k2 == k || fill[(size_t)part[j] * K + k2] >= T) continue;
               const Type& c2 = bestCaps[k2];
               if (type[j][0] > c2[0] || type[j][1] > c2[1] || type[j][2] > c2[2] || !((c2[3] >> type[j][3]) & 1) || (type[j][4] && c2[4] == 0) || (!type[j][4] && c2[4] == 2)) continue;
               if ((int)entOut[j].size() > nOutNow[k2]) continue;      // would grow the row's entry registers
@@ -842,21 +693,15 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const P
 
   // which lane of its row every state gets (placeLanes above)
   std::vector<std::vector<int>> rowMembers;                    // states of each (member, row)
-  const std::vector<int> laneOf = placeLanes(N, G, K, T, edges, inOf, part, rowOfState, segOfRow, attOf, &rowMembers);
+  const std::vector<int> laneOf = placeLanes(N, G, K, T, edges, inOf, part, rowOfState, &rowMembers);
 
   // row shapes as used, S stripes
-  p.rows.assign(K, RowShape{0, -1, -1, -2, 0, -1, 0, -1, -2});   // kind / cls / gOut: -1 / -2 / -1 = no entry seen yet
+  p.rows.assign(K, RowShape{0, -1, -1, -2, 0, -1});   // kind / cls / gOut: -1 / -2 / -1 = no entry seen yet
   std::vector<int> needS(K, 0);
   long real = 0;
   for (int j = 0; j < N; ++j) {
     RowShape& r = p.rows[rowOfState[j]];
     r.nOut = std::max(r.nOut, (int)entOut[j].size());
-    if (attOf[j] >= 0) {                      // what the edges from above have in common
-      const Edge& e = edges[candEdge[j]];
-      const int kind = e.isNull ? 2 : 1;
-      r.fkind = r.fkind < 0 ? kind : (r.fkind == kind ? kind : 0);
-      r.fcls = r.fcls == -2 ? e.sc : (r.fcls == e.sc ? r.fcls : -1);
-    }
     for (int e : entOut[j]) {
       const int kind = edges[e].isNull ? 2 : 1;
       r.kind = r.kind < 0 ? kind : (r.kind == kind ? kind : 0);
@@ -864,7 +709,7 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const P
       const int go = part[edges[e].dst] != part[j] ? 1 : 0;
       r.gOut = r.gOut < 0 ? go : (r.gOut == go ? go : 2);
     }
-    if (attOf[j] < 0) needS[rowOfState[j]] |= type[j][1];
+    needS[rowOfState[j]] |= type[j][1];
     real += (long)entOut[j].size();
   }
   p.nSRows = 0;
@@ -872,10 +717,7 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const P
   std::vector<char> rowUsed(K, 0);
   for (int j = 0; j < N; ++j) rowUsed[rowOfState[j]] = 1;
   for (int k = 0; k < K; ++k) if (!rowUsed[k]) p.rows[k].nOut = -1;   // the kernel skips the row
-  for (RowShape& r : p.rows) { if (r.kind < 0) r.kind = 0; if (r.cls == -2) r.cls = -1; if (r.gOut < 0) r.gOut = 0; if (r.fkind < 0) r.fkind = 0; if (r.fcls == -2) r.fcls = -1; }
-  p.nFwdRows = 0;
-  for (int k = 0; k < K; ++k) if (segOfRow[k] == 0 && rowUsed[k]) p.rows[k].fwd = ++p.nFwdRows;      // 1-based index among the F rows
-  for (int k = 0; k < K; ++k) if (segOfRow[k] == 0 && !rowUsed[k]) p.rows[k].nOut = -1;
+  for (RowShape& r : p.rows) { if (r.kind < 0) r.kind = 0; if (r.cls == -2) r.cls = -1; if (r.gOut < 0) r.gOut = 0; }
   for (int k = 0; k < K; ++k) {
     bool full = true;
     for (int g = 0; g < G; ++g) {
@@ -936,19 +778,6 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const P
   }
   p.sameWave = fwd ? (double)fwdSameWave / (double)fwd : 1.0;
 
-  // F rows: per lane, the edge from the state above -- bit 0 valid, bit 1 null edge, [2:4) score class, [4:6) emitted base;
-  // five rows to a 32-bit word (word (f-1)/5, bits 6*((f-1)%5) ...), f = the row's index among the F rows
-  p.nFwdWords = (p.nFwdRows + 4) / 5;
-  p.fwdTab.assign((size_t)G * std::max(p.nFwdWords, 1) * T, 0u);
-  for (int j = 0; j < N; ++j)
-    if (attOf[j] >= 0) {
-      const int row = rowOfState[j], f = p.rows[row].fwd - 1;
-      if (f < 0 || rowOfState[attOf[j]] != row - 1 || laneOf[attOf[j]] != laneOf[j]) return no("internal: a forwarded state is not under its parent");
-      const Edge& e = edges[candEdge[j]];
-      const unsigned bits = 1u | (e.isNull ? 2u : 0u) | ((unsigned)e.sc << 2) | ((unsigned)(e.base & 3) << 4);
-      p.fwdTab[((size_t)part[j] * std::max(p.nFwdWords, 1) + (size_t)(f / 5)) * T + laneOf[j]] |= bits << (6 * (f % 5));
-    }
-
   // fold table: inbox slot r*T + t of a member -> LDS cells of the state behind it: DC byte address >> 3 | SC byte
   // address >> 3 << 16 (0xffff: the state has no S cell); 0: slot unused
   p.foldTab.assign((size_t)G * nInboxRows * T, 0u);
@@ -980,13 +809,13 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const P
   for (int k = 0; k < K; ++k) {
     if (k) rows << ",";
     rows << "{" << p.rows[k].nOut << "," << p.rows[k].sIdx << "," << p.rows[k].kind << "," << p.rows[k].cls << "," << p.rows[k].full << ","
-         << p.rows[k].gOut << "," << p.rows[k].fwd << "," << p.rows[k].fkind << "," << p.rows[k].fcls << "}";
+         << p.rows[k].gOut << "}";
   }
   defs << "-DDNAS_T=" << T << "\n-DDNAS_K=" << K << "\n-DDNAS_D=" << D << "\n-DDNAS_NS=" << p.NSm << "\n-DDNAS_SROWS=" << p.nSRows
-       << "\n-DDNAS_NCLS=" << p.nClasses << "\n-DDNAS_G=" << G << "\n-DDNAS_GROWS=" << nInboxRows << "\n-DDNAS_GSROWS=" << nInboxSRows << "\n-DDNAS_PAIRSWEEP=" << (pairSweep ? 1 : 0) << "\n-DDNAS_FWDWORDS=" << p.nFwdWords << "\n-DDNAS_ROWS=" << rows.str();
+       << "\n-DDNAS_NCLS=" << p.nClasses << "\n-DDNAS_G=" << G << "\n-DDNAS_GROWS=" << nInboxRows << "\n-DDNAS_GSROWS=" << nInboxSRows << "\n-DDNAS_ROWS=" << rows.str();
   p.defines = defs.str();
   p.key = "T" + std::to_string(T) + "K" + std::to_string(K) + "D" + std::to_string(D) + "S" + std::to_string(p.nSRows) + "C" +
-          std::to_string(p.nClasses) + "G" + std::to_string(G) + "X" + std::to_string(nInboxRows) + "x" + std::to_string(nInboxSRows) + (pairSweep ? "p" : "") + "R" + rows.str();
+          std::to_string(p.nClasses) + "G" + std::to_string(G) + "X" + std::to_string(nInboxRows) + "x" + std::to_string(nInboxSRows) + "R" + rows.str();
   p.ok = true;
   return p;
 }

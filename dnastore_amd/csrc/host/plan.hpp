@@ -31,11 +31,8 @@ namespace dnas {
 // null in-edges), and what all entries of the row have in common, which the kernel then does not decode per
 // lane: kind 1 = emit edges only, 2 = null edges only, 0 = both; cls = the common score class or -1;
 // full = every lane of the row holds a state with exactly nOut out-edges (no entry is empty);
-// gOut = 0: every entry of the row points into LDS, 1: every entry into the exchange buffer, 2: mixed;
-// fwd > 0: an "F row" (the fwd-th of the program): every state of the row has ONE in-edge, from the state in the row above in
-// the same thread, and is evaluated from that thread's registers -- no LDS cell, no entry on the parent's side; fkind / fcls:
-// what those edges have in common (1 emit, 2 null, 0 both; score class or -1)
-struct RowShape { int nOut, sIdx, kind, cls, full, gOut, fwd, fkind, fcls; };
+// gOut = 0: every entry of the row points into LDS, 1: every entry into the exchange buffer, 2: mixed
+struct RowShape { int nOut, sIdx, kind, cls, full, gOut; };
 
 struct TierAPlan {
   bool ok = false;
@@ -55,8 +52,6 @@ struct TierAPlan {
   std::vector<uint32_t> entTab;   // [G][nEntries][T]  out-edges, see viterbi_tiera.hip
   std::vector<uint32_t> metaTab;  // [G][K][T]  mdl | ctx<<4 | flags
   std::vector<uint32_t> foldTab;  // [G][nGRows][T]  inbox slot -> LDS cells of its state (DC addr >> 3 | SC addr >> 3 << 16), 0: unused
-  int nFwdRows = 0, nFwdWords = 0;
-  std::vector<uint32_t> fwdTab;   // [G][nFwdWords][T]  F rows: the edge from the state above, 6 bits per row (plan.cpp)
   double score[4] = {0, 0, 0, 0};
   size_t ldsBytes = 0;
   double fillRatio = 0;           // real entries / padded entries
@@ -67,20 +62,18 @@ struct TierAPlan {
   long exchangeCells() const { return (long)G * nGRows * T; }   // cells of one exchange array
 };
 
-constexpr int kPlanVersion = 3;      // bumped when the planner changes what it produces: recorded tuning verdicts name it
+constexpr int kPlanVersion = 4;      // bumped when the planner changes what it produces: recorded tuning verdicts name it
 
-// What the caller (the runtime's tuning run, an option, an experiment) decides about the row program; -1: as the
-// environment says (DNAS_PLAN_FWD, DNAS_PLAN_ORDER), else the default.
-//   forwardedRows  1: with F rows (states evaluated from the registers of the row above), 0: without (default)
-//   order          the order the states are dealt onto the program in: 0 depth first, 1 breadth first (default: what grows in
-//                  the same sweep sits in the same rows and waves), 2 by longest-path level over the machine without the
-//                  edges that close a cycle of the depth-first walk (a state is dealt after ALL its forward predecessors).
-//                  Which of 1 and 2 is faster depends on the machine (s16h74l4c4: 0.565 / 0.581 of the roofline,
-//                  water64.1*l4c4: 0.405 / 0.367); the runtime times them (option autotune).
-//   slack          order 2 only: how far (in eighths, 0 .. 8) a state moves from its earliest level towards its latest one
-//                  (DNAS_PLAN_SLACK; s16h74l4c4: 0.573 of the roofline at 0, 0.599 at 8)
+// What the caller (a tuning record, an option, an experiment) decides about the row program; -1: as the environment says
+// (DNAS_PLAN_ORDER, DNAS_PLAN_SLACK), else the default.
+//   order   the order the states are dealt onto the program in: 0 depth first, 1 breadth first (default: what grows in the
+//           same sweep sits in the same rows and waves), 2 by longest-path level over the machine without the edges that
+//           close a cycle of the depth-first walk (a state is dealt after ALL its forward predecessors).  Which of 1 and 2 is
+//           faster depends on the machine (s16h74l4c4: 0.565 / 0.581 of the roofline, water64.1*l4c4: 0.405 / 0.367):
+//           dnastore_amd/tune/ holds the measured verdicts.
+//   slack   order 2 only: how far (in eighths, 0 .. 8) a state moves from its earliest level towards its latest one
+//           (s16h74l4c4: 0.573 of the roofline at 0, 0.599 at 8)
 struct PlanChoice {
-  int forwardedRows = -1;
   int order = -1;
   int slack = -1;
 };

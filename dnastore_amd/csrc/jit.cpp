@@ -5,10 +5,12 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <mutex>
 #include <sstream>
 #include <stdexcept>
 
@@ -18,6 +20,14 @@ namespace {
 uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
   for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
   return h;
+}
+
+// a name no other writer of the same file uses: several host threads of one process (dnas_decode_fastseqs with device -1) and
+// several processes (one per GPU) may compile or record the same thing at the same time; each writes its own temporary and
+// renames it into place
+std::string tempName(const std::string& path) {
+  static std::atomic<unsigned long> counter{0};
+  return path + "." + std::to_string((long)getpid()) + "." + std::to_string(counter.fetch_add(1)) + ".tmp";
 }
 
 std::string slurp(const std::string& path) {
@@ -59,7 +69,8 @@ std::string kernelCacheDir() {
 #define DNAS_ARCH "gfx950"
 #endif
 
-unsigned long long cacheHash(const std::string& text) { return (unsigned long long)fnv1a(tieraSource(), fnv1a(text + "|" DNAS_ARCH)); }
+unsigned long long textHash(const std::string& text) { return (unsigned long long)fnv1a(text + "|" DNAS_ARCH); }
+unsigned long long kernelSourceHash() { return (unsigned long long)fnv1a(tieraSource()); }
 
 // looked for in the kernel cache first, then among the records shipped with the library (<library dir>/tune/: the verdicts
 // for the fixture and bench machines, regenerated with tools/make_tune_records.sh whenever the kernel source changes)
@@ -72,7 +83,7 @@ std::string cacheNoteRead(const std::string& name) {
 }
 
 void cacheNoteWrite(const std::string& name, const std::string& text) {
-  const std::string dir = kernelCacheDir(), path = dir + "/" + name, tmp = path + "." + std::to_string((long)getpid()) + ".tmp";
+  const std::string dir = kernelCacheDir(), path = dir + "/" + name, tmp = tempName(path);
   mkdir(dir.c_str(), 0755);
   std::ofstream out(tmp);
   if (!out) return;
@@ -82,6 +93,10 @@ void cacheNoteWrite(const std::string& name, const std::string& text) {
 }
 
 std::vector<char> jitCompile(const std::string& defines, const std::string& key) {
+  // one compilation at a time per process: the threads of a multi-device call ask for the same code object, and the second
+  // one finds it in the cache
+  static std::mutex jitMutex;
+  std::lock_guard<std::mutex> lock(jitMutex);
   const std::string src = tieraSource();
   int rtcMajor = 0, rtcMinor = 0;
   (void)hiprtcVersion(&rtcMajor, &rtcMinor);
@@ -125,14 +140,18 @@ std::vector<char> jitCompile(const std::string& defines, const std::string& key)
   hiprtcDestroyProgram(&prog);
   // best-effort cache write (atomic rename; a read-only tree just skips it)
   mkdir(cacheDir.c_str(), 0755);
-  const std::string tmp = cachePath + "." + std::to_string((long)getpid()) + ".tmp";
+  const std::string tmp = tempName(cachePath);
   {
     std::ofstream out(tmp, std::ios::binary);
     if (out) {
       out.write(code.data(), (std::streamsize)code.size());
       out.close();
-      if (rename(tmp.c_str(), cachePath.c_str()) != 0) remove(tmp.c_str());
+      if (!out || rename(tmp.c_str(), cachePath.c_str()) != 0) remove(tmp.c_str());
     }
+  }
+  if (getenv("DNAS_JIT_DUMP")) {          // kernel development: the options this code object was compiled with, next to it
+    std::ofstream note(cachePath + ".defs");
+    if (note) note << defines << "\n";
   }
   return code;
 }

@@ -19,6 +19,8 @@ std::string kernelCacheDir();
 // A small text record next to the cached code objects (plan autotuning decisions): "" when absent; writes are best effort.
 std::string cacheNoteRead(const std::string& name);
 void cacheNoteWrite(const std::string& name, const std::string& text);
-unsigned long long cacheHash(const std::string& text);
+// names of tuning records hash the machine (textHash); the records name the kernel source they were measured with (kernelSourceHash)
+unsigned long long textHash(const std::string& text);
+unsigned long long kernelSourceHash();
 
 }  // namespace dnas

@@ -67,7 +67,6 @@ struct TierALaunch {
   int nReads;
   unsigned long long timeoutTicks;
   const int* colRange;          // bounded-memory decode: [nReads][2] first and last column of this launch (null: whole reads)
-  const unsigned* fwdTab;       // F rows of the program: the edge from the state above, per lane (plan.cpp)
 };
 
 struct dnas_model {
@@ -83,12 +82,10 @@ struct dnas_model {
   uint64_t* dSegSlot = nullptr;
   TracebackWalk* dWalks = nullptr;
   bool waveTraceback = true;    // one wave per read for batches of up to 256 reads (option traceback=thread: never)
-  int persistentGroups = 0;     // tier A: work-groups per fill launch that pull reads from a queue (0: one work-group per read)
   int maxClusters = 1;          // tier C: clusters that fit the GPU at once
   double* dXbuf = nullptr;      // tier C: exchange buffers, one per cluster
   unsigned* dSync = nullptr;    // tier C: sync blocks (64 u32 per cluster)
   unsigned* dFoldTab = nullptr; // tier C: inbox slot -> LDS cells, per member
-  unsigned* dFwdTab = nullptr;  // F rows of the row program
   size_t xStride = 0;           // doubles per cluster in dXbuf
   unsigned long long timeoutTicks = 0;
   std::vector<unsigned> syncCheck;   // host copies of the sync blocks of every launch of the last call (watchdog, placement census)
@@ -200,11 +197,13 @@ int collect_stats(dnas_model* m) {
 
 namespace {
 
-// With or without F rows (host/plan.cpp)?  The answer depends on the machine -- 17 % slower on s16h74l4c4, 7 % faster on
-// water64.1*l4c4 -- and the plan's cost model does not predict it, so it is measured: when a model is first created for a
-// machine, both row programs are built, compiled and timed on a synthetic read (one work-group each), and the verdict is
-// kept next to the cached code objects (kcache/tune_<hash>.txt; the hash covers both plans and the kernel source).
-// the machine's graph (not the error model: the row programs do not depend on it) names the record
+// Which row program serves a machine fastest?  The planner can deal the states breadth first or by longest-path level
+// (host/plan.hpp: PlanChoice); which is best depends on the machine and the plan's cost model does not predict it, so it is
+// measured and RECORDED: dnastore_amd/tune/ ships the verdicts of the fixture and bench machines (tools/make_tune_records.sh:
+// bench-like reads), and a model follows its machine's record.  The record's name hashes the machine's graph (not the error
+// model: the row programs do not depend on it), the work-group shape and the planner version; the kernel source it was
+// measured with is named INSIDE the record ("kernel=<hash>"), so that an edit of the kernel leaves the records in force and
+// tests/test_tune_records.py says which ones to measure again.
 std::string tune_record_name(const dnas_flat_model* fm, int members, int threads) {
   std::string graph((const char*)&fm->n_states, sizeof fm->n_states);
   auto add = [&](const void* ptr, size_t bytes) { graph.append((const char*)ptr, bytes); };
@@ -215,35 +214,44 @@ std::string tune_record_name(const dnas_flat_model* fm, int members, int threads
   add(fm->nin_ptr, ((size_t)fm->n_states + 1) * sizeof(int32_t)); add(fm->nin_src, (size_t)fm->n_null * sizeof(int32_t));
   add(fm->nin_score, (size_t)fm->n_null * sizeof(double));
   char name[64];
-  snprintf(name, sizeof name, "tune_%016llx.txt", dnas::cacheHash(graph));
+  snprintf(name, sizeof name, "tune_%016llx.txt", dnas::textHash(graph));
   return name;
 }
 
-// "order=<o> fwd=<f> ..." -> the choice a record names (false: no record / not readable)
-bool parse_plan_record(const std::string& note, dnas::PlanChoice* choice) {
-  int o = -1, f = -1, sl = 0;
-  if (sscanf(note.c_str(), "order=%d fwd=%d slack=%d", &o, &f, &sl) < 2 || o < 0 || o > 2 || f < 0 || f > 1 || sl < 0 || sl > 8) return false;
+// "order=<o> slack=<s> kernel=<hash> ..." -> the choice a record names (false: no record / not readable)
+bool parse_plan_record(const std::string& note, dnas::PlanChoice* choice, std::string* kernel = nullptr) {
+  int o = -1, sl = 0;
+  char k[32] = "";
+  if (sscanf(note.c_str(), "order=%d slack=%d kernel=%31s", &o, &sl, k) < 2 || o < 0 || o > 2 || sl < 0 || sl > 8) return false;
   choice->order = o;
-  choice->forwardedRows = f;
   choice->slack = sl;
+  if (kernel) *kernel = k;
   return true;
 }
 
-// Which row program serves this machine fastest?  The planner can deal the states breadth first or by longest-path level,
-// with or without F rows (host/plan.hpp: PlanChoice); which is best depends on the machine and the plan's cost model does
-// not predict it, so it is measured: when a model is first created for a tier-A machine, the candidates are built, compiled
-// and timed on synthetic reads (one work-group each), and the verdict is kept next to the cached code objects
-// (kcache/tune_<hash>.txt; dnastore_amd/tune/ ships the verdicts of the fixture and bench machines).
-int tune_row_program(const dnas_flat_model* fm, int device_id, int threads, dnas::PlanChoice* choice) {
-  *choice = dnas::PlanChoice{0, 1, 0};
+// the record of a machine, if there is one: the choice, and a note for dnas_model_tier ("record tune_x.txt" / "... stale: measured
+// with another kernel source")
+bool follow_plan_record(const dnas_flat_model* fm, int members, int threads, dnas::PlanChoice* choice, std::string* note) {
+  const std::string name = tune_record_name(fm, members, threads);
+  std::string kernel;
+  if (!parse_plan_record(dnas::cacheNoteRead(name), choice, &kernel)) { *note = "no tuning record (default row program)"; return false; }
+  char now[32];
+  snprintf(now, sizeof now, "%016llx", dnas::kernelSourceHash());
+  *note = "record " + name + " order=" + std::to_string(choice->order) + " slack=" + std::to_string(choice->slack) +
+          (kernel == now ? "" : " (stale: measured with kernel " + kernel + ", this is " + now + ")");
+  return true;
+}
+
+// autotune=1 and no record: time the candidate programs on synthetic reads once (one launch each), keep the verdict in the
+// kernel cache.  The reads are what a random walk through the machine emits (a code word sequence) with one base in a hundred
+// substituted; the lattice arena of the timing models is the caller's (at most 8 GiB).
+int tune_row_program(const dnas_flat_model* fm, int device_id, int threads, size_t arena_bytes, dnas::PlanChoice* choice) {
+  *choice = dnas::PlanChoice{1, 0};
   const std::string name = tune_record_name(fm, 1, threads);
-  if (parse_plan_record(dnas::cacheNoteRead(name), choice)) return DNAS_OK;
-  // 240 reads of 480 bases of the kind the machine is for: what a random walk through the machine emits (a code word
-  // sequence), with one base in a hundred substituted -- one work-group per CU, about ten milliseconds per program.  (Random
-  // bases would do for a timing, but the programs differ in how a column's values spread, and that depends on the read; and
-  // four work-groups alone on the GPU do not show what a full launch shows: 6.18 against 6.15 ms there, 46.9 against 45.5 ms
-  // per 720-read launch for the two dealing orders on s16h74l4c4.)
-  const int L = 480, nReads = 240;
+  const size_t arena = std::min<size_t>(arena_bytes ? arena_bytes : (size_t)8 << 30, (size_t)8 << 30);
+  const int L = 480;
+  // a read's lattice: (L + 1) columns of 2 lanes of (about) n_states doubles; half the arena holds a launch
+  const int nReads = (int)std::max<size_t>(4, std::min<size_t>(240, arena / 2 / ((size_t)(L + 1) * 2 * 8 * ((size_t)fm->n_states + 2048))));
   std::vector<uint8_t> bases((size_t)L * nReads);
   {
     // (destination, emitted base or -1); the walk stays inside one message: it does not take an edge that reads the
@@ -275,19 +283,14 @@ int tune_row_program(const dnas_flat_model* fm, int device_id, int threads, dnas
   std::vector<double> ll(nReads);
   std::vector<uint8_t> st(nReads);
   // the default first: another candidate has to beat it by 1.5 % (run-to-run differences of one program stay below 0.5 %)
-  const dnas::PlanChoice candidates[] = {{0, 1, 0}, {0, 2, 0}, {0, 2, 8}, {1, 1, 0}};
+  const dnas::PlanChoice candidates[] = {{1, 0}, {2, 0}, {2, 8}};
   double best = 0;
   std::string report;
   for (const dnas::PlanChoice& c : candidates) {
-    if (c.forwardedRows) {
-      const dnas::TierAPlan p = dnas::buildTierAPlan(*fm, threads, c);
-      if (!p.ok || p.nFwdRows == 0) continue;           // no such program for this machine
-    }
     dnas_model* t = nullptr;
-    const std::string options = "tier=A,autotune=0,plan_order=" + std::to_string(c.order) + ",plan_fwd=" + std::to_string(c.forwardedRows) +
-                                ",plan_slack=" + std::to_string(c.slack) + ",threads=" + std::to_string(threads);
-    int rc = dnas_model_create_ex(fm, device_id, (size_t)64 << 30, options.c_str(), &t);
-    if (rc != DNAS_OK) { if (c.order == 1 && !c.forwardedRows) return DNAS_OK; continue; }   // (the creation that asked reports what is wrong)
+    const std::string options = "tier=A,autotune=0,plan_order=" + std::to_string(c.order) + ",plan_slack=" + std::to_string(c.slack) + ",threads=" + std::to_string(threads);
+    int rc = dnas_model_create_ex(fm, device_id, arena, options.c_str(), &t);
+    if (rc != DNAS_OK) { if (c.order == 1) return DNAS_OK; continue; }   // (the creation that asked reports what is wrong)
     dnas_batch_stats s{};
     double fastest = 0;
     for (int rep = 0; rep < 3 && rc == DNAS_OK; ++rep) {          // the first run warms up; the faster of the other two counts
@@ -299,13 +302,14 @@ int tune_row_program(const dnas_flat_model* fm, int device_id, int threads, dnas
     s.fill_ms = fastest;
     if (rc != DNAS_OK || !(s.fill_ms > 0)) continue;
     char item[96];
-    snprintf(item, sizeof item, "  order=%d fwd=%d slack=%d: %.3f ms", c.order, c.forwardedRows, c.slack, s.fill_ms);
+    snprintf(item, sizeof item, "  %d/%d: %.3f ms", c.order, c.slack, s.fill_ms);
     report += item;
     if (best == 0 || s.fill_ms < 0.985 * best) { if (best == 0 || s.fill_ms < best) best = s.fill_ms; *choice = c; }
   }
   if (best == 0) return DNAS_OK;
-  char head[160];
-  snprintf(head, sizeof head, "order=%d fwd=%d slack=%d   (fill of %d synthetic reads of %d bases;", choice->order, choice->forwardedRows, choice->slack, nReads, L);
+  char head[200];
+  snprintf(head, sizeof head, "order=%d slack=%d kernel=%016llx   (fill of %d synthetic reads of %d bases;", choice->order, choice->slack,
+           dnas::kernelSourceHash(), nReads, L);
   dnas::cacheNoteWrite(name, std::string(head) + report + ")\n");
   return DNAS_OK;
 }
@@ -325,9 +329,10 @@ extern "C" int dnas_model_create(const dnas_flat_model* fm, int device_id, size_
 }
 
 // options: "key=value,key=value"; keys tier (A|B|C), cluster (work-groups per read), threads (512 | 1024 per work-group),
-// max_clusters, max_slots, cluster_timeout_s, persistent, traceback, arena_fraction, checkpoint, segment, plan_fwd (row program
-// with F rows: 0 | 1), plan_order (dealing order: 0 depth first, 1 breadth first, 2 longest-path levels), autotune (0: do not
-// time the candidate row programs when neither is given).  A key that is absent falls back to the environment variable DNAS_<KEY>.
+// max_clusters, max_slots, cluster_timeout_s, traceback, arena_fraction, checkpoint, segment, plan_order (dealing order: 0 depth
+// first, 1 breadth first, 2 longest-path levels), plan_slack, records (0: ignore the machine's tuning record), autotune (1: a
+// tier-A machine without a record is timed once and the verdict kept in the kernel cache).  A key that is absent falls back to
+// the environment variable DNAS_<KEY>.
 extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, size_t arena_bytes, const char* options,
                                     dnas_model** out) {
   if (!fm || !out) return dnas::fail(DNAS_E_INVALID, "dnas_model_create: null argument");
@@ -400,13 +405,15 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
     const char want = !force.empty() ? (char)(force[0] & ~0x20) : 0;
     int wantG = 0, wantT = 0;
     dnas::PlanChoice want_;               // -1: not said
-    bool autotune = true;
+    bool autotune = false, records = true;
+    std::string recordNote = "row program forced by option";
     if (const char* s = opt("cluster")) wantG = atoi(s);
     if (const char* s = opt("threads")) wantT = atoi(s);
-    if (const char* s = opt("plan_fwd")) want_.forwardedRows = atoi(s) != 0;
     if (const char* s = opt("plan_order")) want_.order = std::max(0, std::min(2, atoi(s)));
     if (const char* s = opt("plan_slack")) want_.slack = std::max(0, std::min(8, atoi(s)));
     if (const char* s = opt("autotune")) autotune = atoi(s) != 0;
+    if (const char* s = opt("records")) records = atoi(s) != 0;
+    const bool free_ = want_.order < 0 && want_.slack < 0;     // nothing forced: the record decides
     if (want == 'B') {
       m->tierNote = "tier B forced by DNAS_TIER";
     } else {
@@ -414,10 +421,15 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
       if (want != 'C' && wantG < 2) {
         const int threadsA = wantT ? wantT : dnas::kTierAThreads;
         dnas::PlanChoice choiceA = want_;
-        if (want_.forwardedRows < 0 && want_.order < 0 && want_.slack < 0 && autotune) {
-          int rcTune = tune_row_program(fm, device_id, threadsA, &choiceA);
-          if (rcTune != DNAS_OK) return bail(rcTune);
-          if (hipSetDevice(device_id) != hipSuccess) return bail(dnas::fail(DNAS_E_DEVICE, "hipSetDevice failed"));
+        if (free_ && !records) recordNote = "tuning records off (default row program)";
+        if (free_ && records && !follow_plan_record(fm, 1, threadsA, &choiceA, &recordNote) && autotune) {
+          // no record for this machine: time the candidates once (if the machine fits one work-group at all)
+          if (dnas::buildTierAPlan(*fm, threadsA, choiceA).ok) {
+            int rcTune = tune_row_program(fm, device_id, threadsA, arena_bytes, &choiceA);
+            if (rcTune != DNAS_OK) return bail(rcTune);
+            if (hipSetDevice(device_id) != hipSuccess) return bail(dnas::fail(DNAS_E_DEVICE, "hipSetDevice failed"));
+            recordNote = "timed at model creation: order=" + std::to_string(choiceA.order) + " slack=" + std::to_string(choiceA.slack);
+          }
         }
         m->plan = dnas::buildTierAPlan(*fm, threadsA, choiceA);
         if (!m->plan.ok) whyNotA = m->plan.whyNot;
@@ -429,8 +441,8 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
         // (clusters are not timed here -- planning a 258 538-state machine takes seconds per candidate -- but a recorded
         //  verdict is followed: tools/make_tune_records.py times the dealing orders for the bench machines)
         dnas::PlanChoice choiceC = want_;
-        if (want_.forwardedRows < 0 && want_.order < 0 && want_.slack < 0 && autotune)
-          (void)parse_plan_record(dnas::cacheNoteRead(tune_record_name(fm, wantG >= 2 ? wantG : 0, wantT)), &choiceC);
+        if (free_ && !records) recordNote = "tuning records off (default row program)";
+        if (free_ && records) (void)follow_plan_record(fm, wantG >= 2 ? wantG : 0, wantT, &choiceC, &recordNote);
         m->plan = dnas::chooseClusterPlan(*fm, wantG, wantT, choiceC);
         if (!m->plan.ok) m->plan.whyNot = "one work-group: " + whyNotA + "; cluster: " + m->plan.whyNot;
       }
@@ -450,8 +462,6 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
           if (hipMalloc((void**)&m->dEntTab, p.entTab.size() * 4) != hipSuccess ||
               hipMalloc((void**)&m->dMetaTab, p.metaTab.size() * 4) != hipSuccess ||
               hipMalloc((void**)&m->dSlotOf, p.slotOf.size() * 4) != hipSuccess ||
-              hipMalloc((void**)&m->dFwdTab, std::max<size_t>(p.fwdTab.size(), 1) * 4) != hipSuccess ||
-              hipMemcpy(m->dFwdTab, p.fwdTab.data(), p.fwdTab.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
               hipMemcpy(m->dEntTab, p.entTab.data(), p.entTab.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
               hipMemcpy(m->dMetaTab, p.metaTab.data(), p.metaTab.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
               hipMemcpy(m->dSlotOf, p.slotOf.data(), p.slotOf.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
@@ -468,7 +478,7 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
           d.storedLanes = 2;      // tier A keeps S and D in HBM; T lanes are recomputed where needed
           if (p.G == 1) {
             m->tier = 1;
-            m->tierNote = "tier A: " + p.key;
+            m->tierNote = "tier A: " + p.key + "; " + recordNote;
           } else {
             // a cluster lives on one XCD (32 CUs): floor(32 / G) clusters per XCD.  Every cluster owns an exchange
             // buffer (3 arrays of G * GROWS * T cells + the end-of-read reduction cells) and a sync block.
@@ -488,7 +498,7 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
             m->timeoutTicks = (unsigned long long)(seconds * 1e8);   // s_memrealtime counts at 100 MHz
             m->tier = 2;
             m->tierNote = "tier C: " + std::to_string(p.G) + " work-groups per read, " + std::to_string(m->maxClusters) +
-                          " clusters, exchange edges " + std::to_string(p.crossEdges) + ", " + p.key;
+                          " clusters, exchange edges " + std::to_string(p.crossEdges) + ", " + p.key + "; " + recordNote;
           }
         } catch (const std::exception& e) {
           m->tier = 0;
@@ -513,9 +523,8 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
     // (the XCD's 4 MB L2 holds the S history of ~17 work-groups).  Measured on MI355X with the bench
     // workload: three rounds of 30 work-groups per XCD (720 reads) per launch, 48.8 ms, is the best
     // point; 2 x 255 = 510 reads cost 48 ms (a third round on the traceback's XCD), 500 reads 37 ms.
-    // Round 2 re-measured this with persistent work-groups that pull reads from a queue (option persistent=W, kept
-    // for experiments): a round takes 16.0-16.4 ms for any W from 208 to 240 work-groups and 18 ms at 248 (the XCDs'
-    // L2s), with or without the queue -- 3 x 240 stays the best point, and the queue buys nothing at whole rounds.
+    // (Round 2 measured persistent work-groups that pull reads from a queue: a round takes 16.0-16.4 ms for any number
+    // from 208 to 240 and 18 ms at 248, with or without the queue -- 3 x 240 stays the best point; the queue is gone.)
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 1) {
       const int xcds = std::max(1, cus / 32);
@@ -524,7 +533,6 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
   }
   if (m->tier == 2) m->maxSlots = 1 << 20;   // persistent clusters walk any number of reads: a launch is bounded by the arena only
   if (const char* s = opt("max_slots")) m->maxSlots = std::max(1, atoi(s));
-  if (const char* s = opt("persistent")) m->persistentGroups = std::max(0, atoi(s));
   if (const char* s = opt("traceback")) m->waveTraceback = !(s[0] == 't' || s[0] == 'T');
   if (const char* s = opt("checkpoint")) m->checkpointMode = (s[0] == 'a' && s[1] == 'l') ? 1 : (s[0] == 'n' ? 2 : 0);   // auto | always | never
   if (const char* s = opt("segment")) m->segmentCols = std::max(0, atoi(s));
@@ -553,7 +561,6 @@ extern "C" void dnas_model_destroy(dnas_model* m) {
   if (m->dXbuf) (void)hipFree(m->dXbuf);
   if (m->dSync) (void)hipFree(m->dSync);
   if (m->dFoldTab) (void)hipFree(m->dFoldTab);
-  if (m->dFwdTab) (void)hipFree(m->dFwdTab);
   if (m->dEvents) (void)hipFree(m->dEvents);
   if (m->dEvOff) (void)hipFree(m->dEvOff);
   if (m->dEvLen) (void)hipFree(m->dEvLen);
@@ -674,11 +681,10 @@ int plan_call(const dnas_model* m, int64_t n_reads, const uint64_t* read_offsets
   size_t used = 0;
   for (int64_t i = 0; i < nSeg; ++i) cp->columns += lenOf(i) + 1;
   // one work-group per read: equal batches rather than full ones and a remainder (a launch costs whole rounds of
-  // work-groups).  Persistent work-groups that pull reads from a queue: full batches (a multiple of the work-groups)
-  // and a remainder, which then only costs the rounds it needs.
+  // work-groups)
   const int64_t nPlain = n_reads - nSeg;
   const int64_t nFull = std::max<int64_t>(1, (nPlain + m->maxSlots - 1) / m->maxSlots);
-  const int64_t perBatch = (m->tier == 1 && m->persistentGroups > 0) ? m->maxSlots : (nPlain + nFull - 1) / nFull;
+  const int64_t perBatch = (nPlain + nFull - 1) / nFull;
   for (int64_t i = nSeg; i < n_reads; ++i) {
     const uint64_t L = (uint64_t)lenOf(i);
     const size_t need = colDoubles * (size_t)(L + 1) + 8;   // + a spare cell (tier A, local mode: S(N-1, L) before its overwrite)
@@ -731,12 +737,8 @@ struct FillLauncher {
       return DNAS_OK;
     }
     TierALaunch la{m->argsA, m->dEntTab, m->dMetaTab, d_bases, m->dReadOff, batchRead, slots,
-                   m->arena, d_out_loglike, m->dRounds, nullptr, nullptr, nullptr, 0, nB, 0ull, colRange, m->dFwdTab};
+                   m->arena, d_out_loglike, m->dRounds, nullptr, nullptr, nullptr, 0, nB, 0ull, colRange};
     unsigned grid = (unsigned)nB;
-    if (m->tier == 1 && m->persistentGroups > 0 && nB > m->persistentGroups && !colRange) {
-      grid = (unsigned)m->persistentGroups;      // the work-groups pull the reads beyond the first `grid` from a queue
-      HIP_TRY(hipMemsetAsync(m->dRounds + 9, 0, sizeof(unsigned long long), m->stream));
-    }
     int nClusters = 0;
     if (m->tier == 2) {
       // a cluster of G work-groups per read, persistent over the reads of the launch.  Blocks b and b + 8 share
@@ -1123,10 +1125,10 @@ extern "C" int dnas_tiera_plan_tables(const dnas_flat_model* fm, int32_t* row_sh
 extern "C" int dnas_tiera_precompile(const dnas_flat_model* fm, char* note, size_t note_cap) {
   if (!fm) return dnas::fail(DNAS_E_INVALID, "null argument");
   try {
-    // the row program a model of this machine will run: as the environment says, else as a recorded verdict says
-    // (tune_forwarded_rows), else the plain one
+    // the row program a model of this machine will run: as the environment says, else as its tuning record says, else the
+    // default one
     dnas::PlanChoice choice;
-    if (!getenv("DNAS_PLAN_FWD") && !getenv("DNAS_PLAN_ORDER") && !getenv("DNAS_PLAN_SLACK"))
+    if (!getenv("DNAS_PLAN_ORDER") && !getenv("DNAS_PLAN_SLACK") && !(getenv("DNAS_RECORDS") && atoi(getenv("DNAS_RECORDS")) == 0))
       (void)parse_plan_record(dnas::cacheNoteRead(tune_record_name(fm, 1, dnas::kTierAThreads)), &choice);
     const dnas::TierAPlan p = dnas::buildTierAPlan(*fm, dnas::kTierAThreads, choice);
     std::string msg;
@@ -1175,7 +1177,7 @@ extern "C" int dnas_tierc_precompile(const dnas_flat_model* fm, int32_t members,
   if (!fm) return dnas::fail(DNAS_E_INVALID, "null argument");
   try {
     dnas::PlanChoice choice;      // as a model of this machine will be planned: the environment, else its tuning record
-    if (!getenv("DNAS_PLAN_FWD") && !getenv("DNAS_PLAN_ORDER") && !getenv("DNAS_PLAN_SLACK"))
+    if (!getenv("DNAS_PLAN_ORDER") && !getenv("DNAS_PLAN_SLACK") && !(getenv("DNAS_RECORDS") && atoi(getenv("DNAS_RECORDS")) == 0))
       (void)parse_plan_record(dnas::cacheNoteRead(tune_record_name(fm, members >= 2 ? members : 0, 0)), &choice);
     const dnas::TierAPlan p = dnas::chooseClusterPlan(*fm, members, 0, choice);
     if (!p.ok) return dnas::fail(DNAS_E_UNSUPPORTED, p.whyNot);
@@ -1237,26 +1239,11 @@ extern "C" int dnas_tune_record_name(const dnas_flat_model* fm, int32_t members,
   return DNAS_OK;
 }
 
-// Analysis / test aid: the F rows of the tier-A plan (rows whose states are evaluated from the registers of the row above).
-// fwd_rows[rows][3] = {index among the F rows (0: not an F row), kind of the edges from above (1 emit, 2 null, 0 both), their
-// common score class or -1}; fwd_tab[members][n_words][threads]: 6 bits per F row and lane (layout: csrc/host/plan.cpp).
-extern "C" int dnas_tiera_plan_forwarded(const dnas_flat_model* fm, int32_t members, int32_t* fwd_rows, uint32_t* fwd_tab, size_t fwd_cap,
-                                         int32_t* n_words) {
-  if (!fm || !n_words) return dnas::fail(DNAS_E_INVALID, "null argument");
-  try {
-    const dnas::TierAPlan p = members == 1 ? dnas::buildTierAPlan(*fm) : dnas::chooseClusterPlan(*fm, members, 0);
-    if (!p.ok) return dnas::fail(DNAS_E_UNSUPPORTED, p.whyNot);
-    *n_words = p.nFwdWords;
-    if (fwd_rows)
-      for (int k = 0; k < p.K; ++k) { fwd_rows[3 * k] = p.rows[k].fwd; fwd_rows[3 * k + 1] = p.rows[k].fkind; fwd_rows[3 * k + 2] = p.rows[k].fcls; }
-    if (fwd_tab) {
-      if (fwd_cap < (size_t)p.G * p.nFwdWords * p.T) return dnas::fail(DNAS_E_INVALID, "forward table buffer too small");
-      if (p.nFwdWords > 0) memcpy(fwd_tab, p.fwdTab.data(), (size_t)p.G * p.nFwdWords * p.T * sizeof(uint32_t));
-    }
-    return DNAS_OK;
-  } catch (const std::exception& e) {
-    return dnas::fail(DNAS_E_DEVICE, e.what());
-  }
+// The hash of the fill kernel's source as this library carries it (what a tuning record names as "kernel=").
+extern "C" int dnas_kernel_source_hash(char* out, size_t cap) {
+  if (!out || cap < 17) return dnas::fail(DNAS_E_INVALID, "dnas_kernel_source_hash: bad argument");
+  snprintf(out, cap, "%016llx", dnas::kernelSourceHash());
+  return DNAS_OK;
 }
 
 extern "C" int dnas_model_cluster_census(dnas_model* m, int32_t* clusters, int32_t* split) {

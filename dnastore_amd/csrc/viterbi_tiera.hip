@@ -35,9 +35,8 @@
 // Compile-time parameters (-D):  DNAS_T threads, DNAS_K rows, DNAS_D dup lanes,
 //   DNAS_NS slots per member (= K*T), DNAS_SROWS S stripes, DNAS_NCLS distinct edge scores,
 //   DNAS_G members per cluster, DNAS_GROWS inbox slots per thread, the first DNAS_GSROWS of them with an S cell,
-//   DNAS_ROWS  brace list of {out-edge entries (-1: row left empty), S stripe or -1, kind, cls, full, gOut, fwd, fkind, fcls}
+//   DNAS_ROWS  brace list of {out-edge entries (-1: row left empty), S stripe or -1, kind, cls, full, gOut}
 //              per row; what all entries of a row have in common is not decoded per lane.
-//   DNAS_FWDWORDS  32-bit words per thread that describe the edges into the F rows (6 bits per row)
 #ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>   // hiprtc provides the device runtime implicitly
 #endif
@@ -49,10 +48,7 @@
 // kind: 1 emit edges only, 2 null edges only, 0 both; cls: common score class or -1; full: no empty entry;
 // gOut: 0 every entry of the row points into LDS, 1 every entry into another member's inbox, 2 mixed (bit 2
 // of the entry tells)
-// fwd > 0: an F row, the fwd-th of the program: every state of the row has ONE in-edge, from the state in the row above in the
-// same thread, and is evaluated from that thread's registers (no LDS cell; the parent has no entry for that edge);
-// fkind / fcls: what those edges have in common (1 emit, 2 null, 0 both; score class or -1)
-struct RowShape { int nOut, sIdx, kind, cls, full, gOut, fwd, fkind, fcls; };
+struct RowShape { int nOut, sIdx, kind, cls, full, gOut; };
 constexpr RowShape kRows[DNAS_K] = {DNAS_ROWS};
 
 constexpr bool rowLive(int k) { return kRows[k].nOut >= 0; }      // nOut -1: the plan left the row empty
@@ -83,18 +79,6 @@ __device__ __forceinline__ void static_for(F&& f) {
 #endif
 #ifndef DNAS_GSROWS
 #define DNAS_GSROWS DNAS_GROWS
-#endif
-#ifndef DNAS_PAIRSWEEP
-#define DNAS_PAIRSWEEP 0
-#endif
-#ifndef DNAS_FWDWORDS
-#define DNAS_FWDWORDS 0
-#endif
-#ifndef DNAS_ENT_ONDEMAND
-#define DNAS_ENT_ONDEMAND 0
-#endif
-#ifndef DNAS_EARLY_OFFERS
-#define DNAS_EARLY_OFFERS 1   // one work-group per read: a column's emit offers are made inside phase C of the column before
 #endif
 
 // kernel-argument block (mirrors runtime.hip TierAArgs)
@@ -192,7 +176,7 @@ constexpr double kFresh = __builtin_huge_val();   // "not evaluated in this colu
 // reduction.  Sync block of one cluster (64 u32): [0] GE, [1] abort,
 // [2, 2+G) idle word per member, [40] placement census (OR of 1 << XCC id).
 constexpr int G_ = DNAS_G;
-constexpr bool kEarlyOffers = DNAS_EARLY_OFFERS != 0 && DNAS_G == 1;
+constexpr bool kEarlyOffers = DNAS_G == 1;   // one work-group per read: a column's emit offers are made inside phase C of the column before
 constexpr unsigned kCells = (unsigned)DNAS_G * DNAS_GROWS * DNAS_T;
 constexpr unsigned kXStride = 3u * kCells + 8u;   // doubles per cluster
 
@@ -205,8 +189,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
                    unsigned long long* __restrict__ roundsTotal,
                    double* __restrict__ xbuf, unsigned* __restrict__ syncWords, const unsigned* __restrict__ foldTab,   // [G][GROWS][T]
                    int nClusters, int nReads, unsigned long long timeoutTicks,
-                   const int* __restrict__ colRange,     // [nReads][2] first and last column to fill, or null: 0 .. L
-                   const unsigned* __restrict__ fwdTab) {  // [DNAS_FWDWORDS][T]
+                   const int* __restrict__ colRange) {   // [nReads][2] first and last column to fill, or null: 0 .. L
   extern __shared__ double lds[];
   extern __shared__ unsigned ldsU[];
   constexpr int T = DNAS_T, K = DNAS_K, D_ = DNAS_D, lanes = 2, NSm = DNAS_NS, NS = DNAS_NS * DNAS_G;   // stored lanes: S, D
@@ -239,7 +222,6 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
     entTab += (size_t)member * kEntries * T;
     metaTab += (size_t)member * K * T;
     foldTab += (size_t)member * DNAS_GROWS * T;
-    fwdTab += (size_t)member * (DNAS_FWDWORDS > 0 ? DNAS_FWDWORDS : 1) * T;
     if (tid == 0) {
       unsigned xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -257,15 +239,10 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
 #define FOLD_SC(f) (((f) >> 16) << 3)
 #define FOLD_HAS_SC(f) ((f) != 0u && ((f) >> 16) != 0xffffu)
 
-  // the out-edge entries: in registers for the whole launch, or (DNAS_ENT_ONDEMAND: the 28-row programs of 512-thread
-  // work-groups would spill) fetched from the table where a row offers -- coalesced, L2 resident
-#if DNAS_ENT_ONDEMAND
-#define ENTRY(i) (entTab[(size_t)(i) * T + opaque((unsigned)tid)])
-#else
+  // the out-edge entries: in registers for the whole launch
   unsigned E[kEntries];
   static_for<0, kEntries>([&](auto m) { E[m.value] = entTab[(size_t)m.value * T + tid]; });
 #define ENTRY(i) opaque(E[i])
-#endif
 #define META(k) (metaTab[(size_t)(k) * T + tid])
   // score of an edge by class: class 0 is 0.0 (adding it is the identity on every value that occurs)
   auto withScore = [&](double v, unsigned cls) -> double {
@@ -279,27 +256,6 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
     if constexpr (c == 0) return v;
     else if constexpr (c > 0) return v + a.score[c];
     else return withScore(v, ENT_CLS(en));
-  };
-  // F rows: the edge from the row above, 6 bits per row (bit 0 valid, bit 1 null edge, [2:4) class, [4:6) emitted base)
-  unsigned FW[DNAS_FWDWORDS > 0 ? DNAS_FWDWORDS : 1];
-  static_for<0, DNAS_FWDWORDS>([&](auto m) { FW[m.value] = fwdTab[(size_t)m.value * T + tid]; });
-#define FWD_BITS(k) ((opaque(FW[(kRows[k].fwd - 1) / 5]) >> (6 * ((kRows[k].fwd - 1) % 5))) & 63u)
-  // what the state above offers along that edge.  Emit edge (viterbi.cpp:123-125): max(D + delExtend, S + delOpen) + score
-  // into D; null edge (viterbi.cpp:137-151): D + score into D, S + score into S -- the very operations of the push path
-  auto fromAbove = [&](auto kc, double sUp, double dUp, double& dIn, double& sIn) {
-    constexpr int k = kc.value;
-    const unsigned fw = FWD_BITS(k);
-    dIn = kNegInf; sIn = kNegInf;
-    if (fw & 1u) {
-      auto sc = [&](double v) -> double {
-        constexpr int c = kRows[k].fcls;
-        if constexpr (c == 0) return v;
-        else if constexpr (c > 0) return v + a.score[c];
-        else return withScore(v, (fw >> 2) & 3u);
-      };
-      if (kRows[k].fkind == 2 || (kRows[k].fkind == 0 && (fw & 2u))) { dIn = sc(dUp); sIn = sc(sUp); }
-      else dIn = sc(dmax(dUp + a.delExtend, sUp + a.delOpen));
-    }
   };
   // own accumulators: byte addresses
   const unsigned ownB = (unsigned)tid * 8u;
@@ -387,9 +343,6 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
     }
   };
 
-  // Tier A with fewer work-groups than reads (a persistent launch): a work-group that has finished a read takes the
-  // next one from the launch's queue word, roundsTotal[9] (zeroed by the launcher); reads are sorted longest first.
-  if constexpr (G_ == 1) { if (nReads > (int)gridDim.x) rEnd = nReads; }
   for (int r = rFirst; r < rEnd && !aborted; ) {
   const int read = batchRead[r];
   const unsigned char* seq = bases + readOff[read];
@@ -484,28 +437,11 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
         });
         __syncthreads();
       }
-      // (last row first: an F row takes what the state above offers from that row's S of the previous column, which is
-      //  still in its register)
-      static_for<0, K>([&](auto kr) {
-        constexpr int k = K - 1 - kr.value;
+      static_for<0, K>([&](auto kc) {
+        constexpr int k = kc.value;
         if constexpr (rowLive(k)) {
-          if constexpr (kRows[k].fwd > 0) {
-            const unsigned fw = FWD_BITS(k);
-            double off = kNegInf;
-            if constexpr (kRows[k].fkind != 2) {
-              if ((fw & 1u) && (kRows[k].fkind == 1 || !(fw & 2u))) {
-                constexpr int c = kRows[k].fcls;
-                double v = S[k - 1];
-                if constexpr (c > 0) v = v + a.score[c];
-                else if constexpr (c < 0) v = withScore(v, (fw >> 2) & 3u);
-                off = (v + a.noGap) + ldsRead(ldsB, (unsigned)kTabBase + 32u + (unsigned)x * 8u + ((fw >> 4) & 3u) * 32u);
-              }
-            }
-            S[k] = dmax(off, Dv[k]);
-          } else {
-            S[k] = dmax(ldsRead(ldsB, DC_OWN(k)), Dv[k]);   // Dv: T1(pos-1) + sub[ctx1][x_pos], left there by phase C
-            ldsWrite(ldsB, DC_OWN(k), kNegInf);
-          }
+          S[k] = dmax(ldsRead(ldsB, DC_OWN(k)), Dv[k]);   // Dv: T1(pos-1) + sub[ctx1][x_pos], left there by phase C
+          ldsWrite(ldsB, DC_OWN(k), kNegInf);
           Dv[k] = kFresh;
         }
       });
@@ -565,7 +501,6 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
             }
           });
         }
-        bool grewAbove = false;      // the row evaluated last grew in this sweep (what an F row below it looks at)
         // One row of the sweep; dIn / scIn: its accumulators as read.
         auto rowEval = [&](auto kc, double dIn, double scIn) {
           constexpr int k = kc.value, o = rowOffset(k);
@@ -575,11 +510,10 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
           // moved.  The first sweep of a column finds Dv == kFresh (no D cell is ever +inf) and offers
           // the starting values.
           double d = dIn, s = S[k];
-          constexpr bool sFed = kRows[k].sIdx >= 0 || (kRows[k].fwd > 0 && kRows[k].fkind != 1);   // something offers into S
+          constexpr bool sFed = kRows[k].sIdx >= 0;   // something offers into S
           if constexpr (sFed) s = dmax(s, scIn);
           bool grew = d != Dv[k];
           if constexpr (sFed) grew = grew || s != S[k];
-          grewAbove = grew;
           if (grew) {
             changed = 1;
             s = dmax(s, d + a.delEnd);                                 // viterbi.cpp:114-115
@@ -618,39 +552,14 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
             });
           }
         };
-#if DNAS_PAIRSWEEP
-        // rows two at a time: the accumulators of both are on their way before the first is evaluated (the plan lays a
-        // chain along rows of one parity, so the second row's cells rarely depend on what the first one offers)
-        static_for<0, K / 2>([&](auto mc) {
-          constexpr int k0 = 2 * mc.value, k1 = k0 + 1;
-          double dA = kNegInf, sA = kNegInf, dB = kNegInf, sB = kNegInf;
-          if constexpr (rowLive(k0)) { dA = ldsRead(ldsB, DC_OWN(k0)); if constexpr (kRows[k0].sIdx >= 0) sA = ldsRead(ldsB, SC_OWN(k0)); }
-          if constexpr (rowLive(k1)) { dB = ldsRead(ldsB, DC_OWN(k1)); if constexpr (kRows[k1].sIdx >= 0) sB = ldsRead(ldsB, SC_OWN(k1)); }
-          rowEval(IntC<k0>{}, dA, sA);
-          rowEval(IntC<k1>{}, dB, sB);
-        });
-#else
         static_for<0, K>([&](auto kc) {
           constexpr int k = kc.value;
           if constexpr (!rowLive(k)) return;
-          if constexpr (kRows[k].fwd > 0) {
-            // the cells of an F row are a function of the row above: nothing to do unless that row grew in this sweep
-            // (in the first sweep of a column every row does)
-            if (__any(grewAbove)) {
-              double dIn, sIn;
-              fromAbove(kc, S[k - 1], Dv[k - 1], dIn, sIn);
-              rowEval(kc, dIn, sIn);
-            } else {
-              grewAbove = false;
-            }
-          } else {
-            double sc = kNegInf;
-            const double d = ldsRead(ldsB, DC_OWN(k));
-            if constexpr (kRows[k].sIdx >= 0) sc = ldsRead(ldsB, SC_OWN(k));
-            rowEval(kc, d, sc);
-          }
+          double sc = kNegInf;
+          const double d = ldsRead(ldsB, DC_OWN(k));
+          if constexpr (kRows[k].sIdx >= 0) sc = ldsRead(ldsB, SC_OWN(k));
+          rowEval(kc, d, sc);
         });
-#endif
         ++rounds;
         if constexpr (G_ > 1) {
           // fold the inbox: a cell that raises its state's LDS accumulator counts like an offer of this wave
@@ -781,7 +690,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
         static_for<0, K>([&](auto kc) {
           constexpr int k = kc.value;
           if constexpr (rowLive(k)) {
-            if constexpr (kRows[k].fwd == 0) ldsWrite(ldsB, DC_OWN(k), kNegInf);
+            ldsWrite(ldsB, DC_OWN(k), kNegInf);
             if constexpr (kRows[k].sIdx >= 0) ldsWrite(ldsB, SC_OWN(k), kNegInf);
           }
         });
@@ -825,7 +734,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
           const double s = S[k];
           const int mdl = (int)(metaG[k - k0] & 15u);
           if constexpr (!kEarlyOffers) {
-            if constexpr (kRows[k].fwd == 0) ldsWrite(ldsB, DC_OWN(k), kNegInf);
+            ldsWrite(ldsB, DC_OWN(k), kNegInf);
             if constexpr (kRows[k].sIdx >= 0) ldsWrite(ldsB, SC_OWN(k), kNegInf);
           }
           // T1(pos): chain from the deepest element (i = D-1) to i = 0.  Nearly every state has a
@@ -925,15 +834,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
     if constexpr (G_ > 1) { if (owner) outLoglike[read] = red[0]; }
   }
   __syncthreads();             // red[] is free again
-  if constexpr (G_ > 1) {
-    r += rStep;
-  } else {
-    if (rEnd == rFirst + 1) break;
-    if (tid == 0) *geL = (unsigned)gridDim.x + (unsigned)atomicAdd(roundsTotal + 9, 1ull);
-    __syncthreads();
-    r = (int)*geL;
-    __syncthreads();
-  }
+  r += rStep;
   }   // reads of this work-group / cluster
   if (tid == 0) atomicAdd(roundsTotal, (unsigned long long)rounds);
 }

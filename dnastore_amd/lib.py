@@ -114,7 +114,7 @@ def lib():
         "dnas_tierc_plan": (ctypes.c_int, [P(FlatModelC), ctypes.c_int32, vp, vp, vp, sz, vp, vp, vp, vp, vp]),
         "dnas_model_cluster_census": (ctypes.c_int, [vp, vp, vp]),
         "dnas_tune_record_name": (ctypes.c_int, [vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_char_p, ctypes.c_size_t]),
-        "dnas_tiera_plan_forwarded": (ctypes.c_int, [vp, ctypes.c_int32, vp, vp, ctypes.c_size_t, vp]),
+        "dnas_kernel_source_hash": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t]),
         "dnas_model_last_stats": (ctypes.c_int, [vp, P(BatchStatsC)]),
         "dnas_model_read_lattice": (ctypes.c_int, [vp, i64, i64, vp]),
         "dnas_fwdback_estep": (ctypes.c_int, [P(MutatorParamsC), ctypes.c_int, i64] + [vp] * 8 + [ctypes.c_int, vp, vp, vp]),

@@ -130,12 +130,13 @@ int dnas_model_create(const dnas_flat_model *fm, int device_id, size_t arena_byt
  * fill launch), cluster_timeout_s (tier C watchdog per lattice column), checkpoint = auto | always | never and
  * segment = columns (bounded-memory decode of reads whose lattice -- the reference's ViterbiMatrix::cell,
  * viterbi.h:48-50 -- does not fit the arena: segments of the lattice are filled from checkpoints and traced back one
- * after the other; results are bit-identical), traceback = thread, persistent, arena_fraction, plan_order = 0 | 1 | 2, plan_slack = 0 .. 8 and
- * plan_fwd = 0 | 1 (the row program: states dealt depth first / breadth first / by longest-path level, there with that many
- * eighths of the room between a state's earliest and latest level used; with rows that are evaluated from the registers of
- * the row above.  None given: the machine's tuning record decides -- shipped in <library dir>/tune/, or left in
- * the kernel cache by the timing run of the first model of an unknown tier-A machine; autotune = 0: the default program).  A key that is absent
- * falls back to the environment variable DNAS_<KEY IN UPPER CASE>. */
+ * after the other; results are bit-identical), traceback = thread, arena_fraction, plan_order = 0 | 1 | 2 and plan_slack = 0 .. 8
+ * (the row program: states dealt depth first / breadth first / by longest-path level, there with that many eighths of the
+ * room between a state's earliest and latest level used.  None given: the machine's tuning record decides -- shipped in
+ * <library dir>/tune/, or found in the kernel cache; records = 0: the default program; autotune = 1: a tier-A machine
+ * without a record is timed when its first model is created and the verdict kept in the kernel cache).  dnas_model_tier
+ * names the program and the record that chose it.  A key that is absent falls back to the environment variable
+ * DNAS_<KEY IN UPPER CASE>. */
 int dnas_model_create_ex(const dnas_flat_model *fm, int device_id, size_t arena_bytes, const char *options,
                          dnas_model **out);
 void dnas_model_destroy(dnas_model *model);
@@ -193,17 +194,13 @@ int dnas_tierc_plan(const dnas_flat_model *fm, int32_t members, int32_t *info, i
 int dnas_model_cluster_census(dnas_model *model, int32_t *clusters, int32_t *split);
 /* The file name of a machine's row-program tuning record -- members = 1: as tier A (threads = 0: 1024); members = 0 or >= 2: as
  * tier C with the smallest / that cluster (threads as given to the model, 0 = the planner's choice) --: "tune_<hash>.txt", looked
- * for in the kernel cache and in <library dir>/tune/.  A record starts with "order=<0|1|2> fwd=<0|1> slack=<0..8>" (options
- * plan_order, plan_fwd, plan_slack). */
+ * for in the kernel cache and in <library dir>/tune/.  The name hashes the machine's graph, the work-group shape and the
+ * planner version.  A record starts with "order=<0|1|2> slack=<0..8> kernel=<hash>" (options plan_order, plan_slack; the
+ * hash of the kernel source the verdict was measured with, see dnas_kernel_source_hash). */
 int dnas_tune_record_name(const dnas_flat_model *fm, int32_t members, int32_t threads, char *out, size_t cap);
-/* Analysis / test aid: the F rows of the plan (members = 1: tier A, else the tier-C plan as dnas_tierc_plan describes it) --
- * rows whose states have one in-edge, from the state in the row above in the same thread, and are evaluated from that
- * thread's registers instead of an LDS accumulator.  fwd_rows[rows][3] = {index among the F rows (0: not one), kind of the
- * edges from above (1 emit, 2 null, 0 both), common score class or -1}; fwd_tab[members][*n_words][threads]: per F row and
- * lane 6 bits (bit 0 valid, bit 1 null edge, [2:4) class, [4:6) emitted base), five rows to a word.  Outputs other than
- * n_words may be NULL. */
-int dnas_tiera_plan_forwarded(const dnas_flat_model *fm, int32_t members, int32_t *fwd_rows, uint32_t *fwd_tab, size_t fwd_cap,
-                              int32_t *n_words);
+/* The hash of the fill kernel's source as this library carries it, 16 hex digits: what the tuning records name as
+ * "kernel=".  A record measured with another source is still followed; dnas_model_tier then says "stale". */
+int dnas_kernel_source_hash(char *out, size_t cap);
 
 /* Analysis / test aid: where tier A puts each state (lds_index = row*threads + lane; lattice_slot = its
  * position inside a lattice row).  No GPU needed.  DNAS_E_UNSUPPORTED when the machine does not fit tier A. */

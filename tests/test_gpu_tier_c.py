@@ -190,27 +190,3 @@ def test_config4b_hamming74_water64_composite_tier_c(da, oracle_mod, ref_data):
     assert da.symbolsToBytes(out[0]) == payload and da.symbolsToBytes(out[1]) == payload
     assert ll[1] < ll[0]
     dec.close()
-
-
-@pytest.mark.parametrize("mach,fa,flags,members,threads", [
-    ("s16h74l4c4.json", "hello.s16h74.del.fa", dict(global_=True), 3, 512),
-    ("s16h74l4c4.json", "hello.s16h74.del.fa", dict(), 2, 1024),
-    ("s16mr2l4c4.json", "hello.s16mr2.fa", dict(global_=True), 2, 512),
-])
-def test_tier_c_forwarded_rows_full_lattice(da, oracle_mod, ref_data, mach, fa, flags, members, threads):
-    """plan_fwd=1 on a cluster: runs of states inside a member hang under each other in F rows (evaluated from the registers of
-    the row above); every cell is still the oracle's."""
-    O = oracle_mod
-    path = os.path.join(ref_data, mach)
-    dec = da.ViterbiDecoder(da.Machine.fromFile(path), da.MutatorParams.fromFlags(**flags),
-                            options="tier=C,cluster=%d,threads=%d,plan_fwd=1" % (members, threads))
-    orc = O.ViterbiOracle(O.Machine.from_file(path), O.MutatorParams.from_cli(**flags))
-    reads = [seq for _, seq in da.read_fastseqs(os.path.join(ref_data, fa))]
-    out, ll, st = dec.decode(reads)
-    for i, r in enumerate(reads):
-        s, oll, olat = orc.decode(r, want_lattice=True)
-        assert out[i] == s and ll[i] == oll
-        lat = np.ascontiguousarray(dec.lattice(i, len(r)).transpose(0, 2, 1))
-        assert np.array_equal(lat.view(np.uint64), olat.view(np.uint64))
-    assert dec.tier.startswith("tier C: %d work-groups" % members)
-    dec.close()

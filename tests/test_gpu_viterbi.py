@@ -57,27 +57,6 @@ def test_full_lattice_bit_exact(da, oracle_mod, ref_data, mach, fa, flags):
     dec.close()
 
 
-def test_full_lattice_with_forwarded_rows(da, oracle_mod, ref_data, monkeypatch):
-    """DNAS_PLAN_FWD=1 (experimental): the row program with F rows -- states evaluated from the registers of the row above
-    instead of an LDS accumulator -- gives the same cells, bit for bit."""
-    O = oracle_mod
-    monkeypatch.setenv("DNAS_PLAN_FWD", "1")
-    for mach, fa, flags in [("s16h74l4c4.json", "hello.s16h74.del.fa", dict(global_=True)), ("s16h74l4c4.json", "hello.s16h74.del.fa", dict()),
-                            ("h74l4c4.json", "hello.h74.sub.fa", dict(global_=True))]:
-        path = os.path.join(ref_data, mach)
-        dec = da.ViterbiDecoder(da.Machine.fromFile(path), da.MutatorParams.fromFlags(**flags))
-        assert dec.tier.startswith("tier A")
-        orc = O.ViterbiOracle(O.Machine.from_file(path), O.MutatorParams.from_cli(**flags))
-        reads = [seq for _, seq in da.read_fastseqs(os.path.join(ref_data, fa))]
-        out, ll, st = dec.decode(reads)
-        for i, r in enumerate(reads):
-            s, oll, olat = orc.decode(r, want_lattice=True)
-            assert out[i] == s and ll[i] == oll
-            lat = np.ascontiguousarray(dec.lattice(i, len(r)).transpose(0, 2, 1))
-            assert np.array_equal(lat.view(np.uint64), olat.view(np.uint64))
-        dec.close()
-
-
 @pytest.mark.parametrize("flags,noise", [
     (dict(global_=True), dict(sub=0.01)),
     (dict(), dict(sub=0.02, dele=0.01, dup=0.01)),
@@ -296,10 +275,10 @@ def test_arena_replanned_when_the_device_has_less_memory_than_at_creation(da, re
     dec.close()
 
 
-@pytest.mark.parametrize("options", ["plan_order=0", "plan_order=2", "plan_order=2,plan_slack=8", "plan_order=2,plan_slack=3,plan_fwd=1"])
+@pytest.mark.parametrize("options", ["plan_order=0", "plan_order=1", "plan_order=2", "plan_order=2,plan_slack=8", "plan_order=2,plan_slack=3"])
 def test_full_lattice_under_every_dealing_order(da, oracle_mod, ref_data, options):
-    """The row program may be dealt depth first, breadth first (the default of every other test) or by longest-path level, with
-    or without F rows (tuning records pick per machine): the cells are the oracle's every time."""
+    """The row program may be dealt depth first, breadth first (the default without a tuning record) or by longest-path level
+    (the tuning records pick per machine; the other tests run what the records say): the cells are the oracle's every time."""
     O = oracle_mod
     path = os.path.join(ref_data, "s16h74l4c4.json")
     flags = dict(global_=True)
@@ -316,35 +295,37 @@ def test_full_lattice_under_every_dealing_order(da, oracle_mod, ref_data, option
 
 
 def test_row_program_autotune(da, oracle_mod, ref_data, tmp_path, monkeypatch):
-    """autotune=1 (the library's default; the suite runs with DNAS_AUTOTUNE=0): the first model of a machine times the row
-    program with and without F rows on a synthetic read, keeps the verdict in the kernel cache, and later models read it;
-    for the fixture and bench machines the verdict ships with the library (dnastore_amd/tune/) and nothing is timed.
-    Whatever is picked, the results are the plain program's, bit for bit."""
+    """autotune=1 (opt-in): the first model of a tier-A machine WITHOUT a tuning record times the candidate row programs on
+    synthetic reads, keeps the verdict in the kernel cache, and later models read it; for the fixture and bench machines the
+    verdict ships with the library (dnastore_amd/tune/) and nothing is timed.  Whatever is picked, the results are the default
+    program's, bit for bit."""
     from random_machines import random_machine, random_read
     monkeypatch.setenv("DNAS_KCACHE_DIR", str(tmp_path))
-    monkeypatch.setenv("DNAS_AUTOTUNE", "1")
     params = da.MutatorParams.fromFlags(global_=True)
-    # a machine nobody has seen: timed, one record
+    # a machine nobody has seen: without autotune nothing is timed and nothing is written
     text = random_machine(77, 5000)
     m = da.Machine.fromJSON(text)
     reads = [random_read(500 + r, text, max_len=40) for r in range(5)]
-    tuned = da.ViterbiDecoder(m, params)
+    plain = da.ViterbiDecoder(m, params)
+    assert "no tuning record" in plain.tier and not [f for f in os.listdir(tmp_path) if f.startswith("tune_")]
+    want = plain.decode(reads)
+    # with it: timed, one record (the arena of the timing models is the caller's)
+    tuned = da.ViterbiDecoder(m, params, arena_bytes=2 << 30, options="autotune=1")
     notes = [f for f in os.listdir(tmp_path) if f.startswith("tune_")]
     assert len(notes) == 1
     verdict = open(os.path.join(tmp_path, notes[0])).read()
-    assert verdict.startswith("order=") and " fwd=" in verdict
+    assert verdict.startswith("order=") and " kernel=" + da.FlatModel.kernel_source_hash() in verdict
     got = tuned.decode(reads)
     again = da.ViterbiDecoder(m, params)                           # reads the record: no second one appears
-    assert [f for f in os.listdir(tmp_path) if f.startswith("tune_")] == notes and again.tier == tuned.tier
-    plain = da.ViterbiDecoder(m, params, options="plan_fwd=0,plan_order=1")
-    want = plain.decode(reads)
+    assert [f for f in os.listdir(tmp_path) if f.startswith("tune_")] == notes and "record " + notes[0] in again.tier
     assert got[0] == want[0] and np.array_equal(got[1].view(np.uint64), want[1].view(np.uint64)) and np.array_equal(got[2], want[2])
     for d in (tuned, again, plain):
         d.close()
     # a machine with a shipped verdict (dnastore_amd/tune/): nothing is timed, nothing is written
     water = da.Machine.compose(da.Machine.fromFile(os.path.join(ref_data, "water64.1.json")), da.Machine.fromFile(os.path.join(ref_data, "l4c4.json")))
-    shipped = da.ViterbiDecoder(water, params)
-    forced = [da.ViterbiDecoder(water, params, options="plan_fwd=0,plan_order=%d" % v) for v in (1, 2)]
+    shipped = da.ViterbiDecoder(water, params, options="autotune=1")
+    assert "record tune_" in shipped.tier and "stale" not in shipped.tier
+    forced = [da.ViterbiDecoder(water, params, options="plan_order=%d" % v) for v in (1, 2)]
     assert [f for f in os.listdir(tmp_path) if f.startswith("tune_")] == notes
     assert forced[0].tier != forced[1].tier
     wreads = [water.encodeBytes(bytes(range(8 * i, 8 * i + 8))) for i in range(3)]

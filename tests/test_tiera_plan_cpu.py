@@ -67,29 +67,6 @@ def _decode_plan(fm, members):
             out[j].append((dst, cls, base, is_null))
     rows = lds_idx // T
     has_s = shapes[rows, 1] >= 0
-    # F rows (tier A): a state there has ONE in-edge, from the state right above it in the same thread; the parent holds no
-    # entry for it -- the edge is in the forward table
-    fwd_rows, fwd_tab = pl["fwd_rows"], pl["fwd_tab"]
-    for k in range(K):
-        f = int(fwd_rows[k, 0])
-        if f == 0:
-            continue
-        assert k > 0 and shapes[k, 1] < 0, "an F row has a row above it and no S stripe"
-        for g in range(G):
-            for t in range(T):
-                bits = (int(fwd_tab[g, (f - 1) // 5, t]) >> (6 * ((f - 1) % 5))) & 63
-                j = int(state_at[g, k * T + t])
-                if not bits & 1:
-                    assert j < 0, "a state in an F row without an edge from above"
-                    continue
-                parent = int(state_at[g, (k - 1) * T + t])
-                assert j >= 0 and parent >= 0, "forward-table entry without both states"
-                is_null, cls, base = bool(bits & 2), (bits >> 2) & 3, (bits >> 4) & 3
-                assert fwd_rows[k, 1] == 0 or fwd_rows[k, 1] == (2 if is_null else 1)
-                assert fwd_rows[k, 2] < 0 or fwd_rows[k, 2] == cls
-                out[parent].append((j, cls, base, is_null))
-                if is_null:
-                    has_s[j] = True
     # every used inbox slot belongs to exactly one state
     used = fold[fold != 0] & 0xffff if G > 1 else np.zeros(0, dtype=np.uint32)
     per_member = [sorted((fold[g][fold[g] != 0] & 0xffff).tolist()) for g in range(G)] if G > 1 else []
@@ -192,28 +169,6 @@ def test_plan_tables_reproduce_the_oracle_lattice(oracle_mod, ref_data, mach, fa
         S_lat, D_lat = _emulate(fm, da.tokenize(read), local=not flags.get("global_", False), members=members)
         assert np.array_equal(S_lat.view(np.uint64), np.ascontiguousarray(olat[:, :, 0]).view(np.uint64))
         assert np.array_equal(D_lat.view(np.uint64), np.ascontiguousarray(olat[:, :, 1]).view(np.uint64))
-
-
-def test_plan_with_forwarded_rows(oracle_mod, ref_data, monkeypatch):
-    """DNAS_PLAN_FWD=1 (experimental, plan.cpp): rows whose states hang under the state above them in the same thread and have
-    no entry / no LDS cell.  The tables still encode exactly the machine's edges and reproduce the oracle's lattice."""
-    import dnastore_amd as da
-    O = oracle_mod
-    monkeypatch.setenv("DNAS_PLAN_FWD", "1")
-    for mach, fa, flags in [("h74l4c4.json", "hello.h74.sub.fa", dict(global_=True)), ("l4c4.json", "hello.fa", dict())]:
-        path = os.path.join(ref_data, mach)
-        fm = da.FlatModel(da.Machine.fromFile(path), da.MutatorParams.fromFlags(**flags))
-        read = da.read_fastseqs(os.path.join(ref_data, fa))[0][1][:16]                       # pure-Python loops: keep it short
-        orc = O.ViterbiOracle(O.Machine.from_file(path), O.MutatorParams.from_cli(**flags))
-        _, _, olat = orc.decode(read, want_lattice=True)
-        for members in (1, 2):                                                               # tier A, and a cluster of two
-            pl = fm.cluster_plan(members)
-            assert int((pl["fwd_rows"][:, 0] > 0).sum()) >= 1, "no F rows although asked for"
-            under = sum(bin(int(w) & 0x01041041).count("1") for w in pl["fwd_tab"].ravel())     # the valid bits (0, 6, 12, 18, 24)
-            assert under > 0.15 * fm.arrays()["n_states"]
-            S_lat, D_lat = _emulate(fm, da.tokenize(read), local=not flags.get("global_", False), members=members)
-            assert np.array_equal(S_lat.view(np.uint64), np.ascontiguousarray(olat[:, :, 0]).view(np.uint64))
-            assert np.array_equal(D_lat.view(np.uint64), np.ascontiguousarray(olat[:, :, 1]).view(np.uint64))
 
 
 @pytest.mark.parametrize("order,slack", [(0, 0), (2, 0), (2, 8), (2, 3)])

@@ -1,7 +1,7 @@
 """Wider fuzz run than the test suite's: many random machines / error models / reads, GPU against the oracle -- decoded
 string, log-likelihood, status and every lattice cell -- under every way the fill can run: tier A, tier B, tier C (clusters
 of 2-4 work-groups), the bounded-memory decode in segments (tiers A and C; no lattice to compare), and the experimental row
-program with forwarded rows (DNAS_PLAN_FWD=1).
+program dealt by longest-path level (plan_order=2).
   python tools/fuzz_sweep.py 40 [first seed]"""
 import os, sys, random
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,14 +29,10 @@ for case in range(n_cases):
     modes = [("A", "tier=A", False, True), ("B", "tier=B", False, True), ("C", "tier=C,cluster=%d" % members, False, True),
              ("A segments", "tier=A,checkpoint=always,segment=%d" % seg, False, False),
              ("C segments", "tier=C,cluster=%d,checkpoint=always,segment=%d" % (members, seg), False, False),
-             ("A forwarded rows", "tier=A", True, True)]
+             ("A by level", "tier=A,plan_order=2,plan_slack=%d" % (case % 9), False, True)]
     if flags["length"] > 8:
         modes = [mo for mo in modes if mo[0] == "B"]             # more than 8 duplication lanes: the general kernel only
     for mode, options, fwd, has_lattice in modes:
-        if fwd:
-            os.environ["DNAS_PLAN_FWD"] = "1"
-        else:
-            os.environ.pop("DNAS_PLAN_FWD", None)
         try:
             dec = da.ViterbiDecoder(da.Machine.fromJSON(text), da.MutatorParams.fromFlags(**flags), options=options)
         except da.DnasError as e:

@@ -1,17 +1,16 @@
 """Row-program verdicts for the fixture and bench machines, from bench-like reads: for every machine the candidate programs
-(dealing order 1, order 2 with every slack share 0 .. 8, order 1 with F rows: options plan_order, plan_slack, plan_fwd) decode 2160 reads (three launches) -- encoded random payloads with
+(dealing order 1, order 2 with every slack share 0 .. 8: options plan_order, plan_slack) decode 2160 reads (three launches) -- encoded random payloads with
 1 % substitutions, as bench.py makes them -- three times; the fastest fill of the last two runs counts, and a candidate has
-to beat the default (order=1 fwd=0) by 1.5 %.  The records go to the directory given (tools/make_tune_records.sh copies them
-to dnastore_amd/tune/, where the library finds them); their names hash the kernel source and the planner version, so they
-are made again whenever either changes.  (The library's own tuning run, for machines without a record, has no encoder at
+to beat the default (order=1) by 1.5 %.  The records go to the directory given (tools/make_tune_records.sh copies them
+to dnastore_amd/tune/, where the library finds them); their names hash the machine and the planner version, and each names the
+kernel source it was measured with (tests/test_tune_records.py fails when that is no longer the library's).  (The library's own tuning run, for machines without a record, has no encoder at
 hand and uses what a random walk through the machine emits; for s16h74l4c4 that ranks the two dealing orders the other way
 round than real reads do, by 2 % either way.)
   python tools/make_tune_records.py <output directory>"""
 import os, sys, random
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["DNAS_AUTOTUNE"] = "0"
-for k in ("DNAS_PLAN_FWD", "DNAS_PLAN_ORDER"):
+for k in ("DNAS_PLAN_SLACK", "DNAS_PLAN_ORDER"):
     os.environ.pop(k, None)
 import dnastore_amd as da
 import bench
@@ -33,10 +32,10 @@ for name, m, payload, n_reads, members in machines:
     reads = bench.make_reads(m, 0, n_reads, payload_bytes=payload)
     fm = da.FlatModel(m, params)
     results = []
-    candidates = [(1, 0, 0)] + [(2, 0, sl) for sl in (range(9) if members == 1 else (0, 4, 8))] + ([(1, 1, 0)] if members == 1 else [])
-    for order, fwd, slack in candidates:
+    candidates = [(1, 0)] + [(2, sl) for sl in (range(9) if members == 1 else (0, 4, 8))]
+    for order, slack in candidates:
         try:
-            dec = da.ViterbiDecoder(m, params, options="tier=%s,autotune=0,plan_order=%d,plan_fwd=%d,plan_slack=%d" % ("A" if members == 1 else "C", order, fwd, slack))
+            dec = da.ViterbiDecoder(m, params, options="tier=%s,plan_order=%d,plan_slack=%d" % ("A" if members == 1 else "C", order, slack))
         except da.DnasError as e:
             continue
         ms = []
@@ -44,12 +43,13 @@ for name, m, payload, n_reads, members in machines:
             dec.decode(reads)
             ms.append(dec.stats()["fill_ms"])
         dec.close()
-        results.append((order, fwd, slack, min(ms[1:])))
+        results.append((order, slack, min(ms[1:])))
     best = results[0]
-    fastest = min(results, key=lambda r: r[3])
-    if fastest[3] < 0.985 * best[3]:
+    fastest = min(results, key=lambda r: r[2])
+    if fastest[2] < 0.985 * best[2]:
         best = fastest
-    text = "order=%d fwd=%d slack=%d   (fill of %d bench reads, %s;%s)\n" % (best[0], best[1], best[2], n_reads, name, "".join("  %d/%d/%d: %.2f ms" % r for r in results))
+    text = "order=%d slack=%d kernel=%s   (fill of %d bench reads, %s;%s)\n" % (best[0], best[1], da.FlatModel.kernel_source_hash(), n_reads, name,
+                                                                               "".join("  %d/%d: %.2f ms" % r for r in results))
     path = os.path.join(OUT, fm.tune_record_name(members))
     open(path, "w").write(text)
     print(os.path.basename(path), text.strip(), flush=True)

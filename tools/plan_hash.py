@@ -1,5 +1,5 @@
 """Fingerprint of the row programs and tables host/plan.cpp produces for the fixture machines (tier A and clusters of 2 and 3,
-with and without forwarded rows): a refactoring of the planner must leave every line unchanged.
+default dealing order): a refactoring of the planner must leave every line unchanged.
   python tools/plan_hash.py > /tmp/before.txt ; ... ; python tools/plan_hash.py | diff /tmp/before.txt -"""
 import hashlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,8 +23,7 @@ def machines():
 for name, m in machines():
     for glob in (True, False):
         fm = da.FlatModel(m, da.MutatorParams.fromFlags(global_=glob))
-        for fwd in ("0", "1"):
-            os.environ["DNAS_PLAN_FWD"] = fwd
+        for fwd in ("0",):
             for members in ((1, 2, 3) if "mixradar6" not in name else (0,)):
                 try:
                     pl = fm.cluster_plan(members)
@@ -32,7 +31,7 @@ for name, m in machines():
                     print(name, "global" if glob else "local", "fwd", fwd, "members", members, "->", str(e)[:80])
                     continue
                 h = hashlib.sha256()
-                for key in ("shapes", "entries", "meta", "member_of", "lds_index", "lattice_slot", "fold", "fwd_rows", "fwd_tab"):
+                for key in ("shapes", "entries", "meta", "member_of", "lds_index", "lattice_slot", "fold"):
                     h.update(np.ascontiguousarray(pl[key]).tobytes())
                 print(name, "global" if glob else "local", "fwd", fwd, "members", members, "G", pl["G"], "K", pl["K"], "T", pl["T"], "entries", pl["n_entries"],
                       "S", pl["n_s_rows"], h.hexdigest()[:20], flush=True)
