@@ -172,61 +172,69 @@ def cpu_baseline(machine_json, reads, seconds, max_nt=None):
     return out, results
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3, 4], help="index into BASELINE.json configs (default 2: the headline)")
-    ap.add_argument("--variant", default="a", choices=["a", "b"], help="config 3: a = water64.1*l4c4, b = hamming74*dropdot*water64.1*l4c4")
-    ap.add_argument("--reads", type=int, default=0, help="reads (config 4: pairs) per GPU; 0 = the configuration's default")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline time budget (0 = skip)")
-    ap.add_argument("--arena-gb", type=float, default=0.0, help="lattice arena per GPU (0 = the library's default, 60 %% of free HBM)")
-    ap.add_argument("--scatter", action="store_true", help="rank 0 makes every rank's reads and scatters them (RCCL) instead of per-rank generation")
-    ap.add_argument("--timed-only", action="store_true", help="skip the passes outside the timed region (PCIe-inclusive, single-read latency, CPU baseline): "
-                                                              "every launch of the run is then one of the timed steps (profiling)")
-    ap.add_argument("--options", default=None, help='dnas_model_create_ex options, e.g. "max_slots=690"')
-    args = ap.parse_args()
-    if args.config == 4:
-        import bench_fwdback
-        return bench_fwdback.main(args)
+class Ctx:
+    """Ranks, devices and the process group of this run (one process per GPU)."""
 
-    import torch
-    import torch.distributed as dist
+    def __init__(self, gpus):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != gpus:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (gpus, self.world))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this pool's driver
+        # DNAS_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks (the ranks
+        # share the cards, the collectives run on host copies); the measured configuration is always nccl (= RCCL)
+        self.backend = os.environ.get("DNAS_BENCH_BACKEND", "nccl")
+        n_dev = torch.cuda.device_count()          # (counting devices does not initialise the GPU)
+        if n_dev <= 0:
+            raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+        if self.backend != "nccl":
+            self.local_rank %= n_dev
+        self.device = torch.device("cuda", self.local_rank)
+        self.coll_device = self.device if self.backend == "nccl" else torch.device("cpu")
+        if self.world > 1:
+            # the process group first: nothing of this process has touched a GPU before RCCL binds the rank to its device
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.device)
+            else:
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
+        torch.cuda.set_device(self.local_rank)
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+
+    def fence(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def close(self):
+        if self.world > 1:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def viterbi_line(ctx, config, variant, n_reads, steps, warmup, cpu_seconds, timed_only=False, scatter=False, arena_gb=0.0, options=None,
+                 dump_decoded=None):
+    """One BASELINE Viterbi configuration on this run's GPUs -> the JSON line as a dict (rank 0; None elsewhere)."""
     import dnastore_amd as da
     from dnastore_amd import shard
+    torch, dist = ctx.torch, ctx.dist
+    rank, world, device, coll_device = ctx.rank, ctx.world, ctx.device, ctx.coll_device
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    # DNAS_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks (the ranks
-    # share the cards, the collectives run on host copies); the measured configuration is always nccl (= RCCL)
-    backend = os.environ.get("DNAS_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank %= max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    coll_device = device if backend == "nccl" else torch.device("cpu")
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-
-    wl = workload(da, args.config, args.variant)
+    wl = workload(da, config, variant)
     machine = wl["machine"]
-    n_reads = args.reads or wl["default_reads"]
+    n_reads = n_reads or wl["default_reads"]
     params = da.MutatorParams.fromFlags(global_=True)
-    dec = da.ViterbiDecoder(machine, params, device=local_rank, arena_bytes=int(args.arena_gb * 1e9), options=args.options)
+    dec = da.ViterbiDecoder(machine, params, device=ctx.local_rank, arena_bytes=int(arena_gb * 1e9), options=options)
 
     # ---- inputs (untimed): every rank makes its own reads by index; --scatter: rank 0 makes all, RCCL scatter
     my_reads = None
-    if args.scatter:
+    if scatter:
         all_reads = make_reads(machine, 0, n_reads * world, payload_bytes=wl["payload_bytes"]) if rank == 0 else None
         off_all, bases_all = da.pack_reads(all_reads) if rank == 0 else (None, None)
         idx, off, d_bases = shard.scatter_reads(off_all, bases_all, world, rank, coll_device)
@@ -258,27 +266,21 @@ def main():
         dec.sync()
         return shard.gather_results(d_sym.to(coll_device), d_len.to(coll_device), d_ll.to(coll_device), d_st.to(coll_device), world, rank)
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     torch.cuda.synchronize()   # torch's fills of the output buffers are done before the library's streams write them
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
-    fence()
+    ctx.fence()
     t0 = time.perf_counter()
     fill_ms = 0.0
     tb_ms = 0.0
     stats = None
     gathered = None
-    for _ in range(args.steps):
+    for _ in range(steps):
         gathered = step()
         stats = dec.stats()
         fill_ms += stats["fill_ms"]
         tb_ms += stats["traceback_ms"]
-    fence()
+    ctx.fence()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed, float(shard_nt)], dtype=torch.float64, device=coll_device)
     if world > 1:
@@ -290,10 +292,21 @@ def main():
     else:
         total_nt = float(shard_nt)
 
+    line = None
     if rank == 0:
         extra = {}
         cpu = None
-        if world == 1 and not args.timed_only:
+        if dump_decoded and not scatter:
+            # what came back from every rank, in read-index order (rank r made the reads r * n_reads ...): tests compare runs
+            # with different numbers of ranks
+            dump = []
+            for sym_r, len_r, ll_r, st_r in gathered:
+                sym_r, len_r, ll_r, st_r = (x.cpu().numpy() for x in (sym_r, len_r, ll_r, st_r))
+                for i in range(len(len_r)):
+                    dump.append([sym_r[i * cap:i * cap + int(len_r[i])].tobytes().decode(), float(ll_r[i]).hex(), int(st_r[i])])
+            with open(dump_decoded, "w") as f:
+                json.dump(dump, f)
+        if world == 1 and not timed_only:
             # ---- the same shard through the host-pointer entry point (dnas_viterbi_batch): H2D of the reads, D2H of the
             # decoded strings, per-call device buffers -- SURVEY 8(d)'s PCIe-inclusive rate; never `value`
             dec.decode(my_reads[:min(k, 64)])
@@ -301,10 +314,10 @@ def main():
             out_h, ll_h, st_h = dec.decode(my_reads)
             extra["value_pcie_inclusive"] = shard_nt / (time.perf_counter() - tp)
             # ---- BASELINE configs[1] names ONE read: its latency
-            if args.config == 1:
+            if config == 1:
                 # the default plan is the throughput one (512-thread work-groups: the machine on 4 CUs per read); for one
                 # read alone 1024-thread work-groups (5 CUs per read, shorter sweeps) are the faster choice: "threads=1024"
-                dec_lat = da.ViterbiDecoder(machine, params, device=local_rank, options="threads=1024")
+                dec_lat = da.ViterbiDecoder(machine, params, device=ctx.local_rank, options="threads=1024")
                 dec_lat.decode(my_reads[:1])
                 tp = time.perf_counter()
                 dec_lat.decode(my_reads[:1])
@@ -313,9 +326,9 @@ def main():
                 extra["single_read_plan"] = dec_lat.tier[:40]
                 dec_lat.close()
             # ---- parity spot check + CPU baseline (rank 0, N = 1 only), outside the timed region
-            if args.cpu_seconds > 0:
+            if cpu_seconds > 0:
                 max_nt = 256 if machine.nStates() > 100000 else None
-                cpu, results = cpu_baseline(machine.toJSON(), my_reads, args.cpu_seconds, max_nt=max_nt)
+                cpu, results = cpu_baseline(machine.toJSON(), my_reads, cpu_seconds, max_nt=max_nt)
                 sym, olen, ll, st = [x.cpu().numpy() for x in gathered[0]]
                 if max_nt:      # prefixes were decoded on the CPU: decode the same prefixes on the GPU
                     idxs = sorted(results)
@@ -327,47 +340,101 @@ def main():
                     if got[i][0] != s_ref or got[i][1] != ll_ref:
                         raise SystemExit("PARITY FAILURE on read %d: %r/%r vs oracle %r/%r" % (i, got[i][0], got[i][1], s_ref, ll_ref))
                 cpu["parity_checked_reads"] = len(results)
-        value = total_nt * args.steps / elapsed
-        launches = stats["fill_launches"] * args.steps
-        achieved = stats["lattice_bytes"] * args.steps / (fill_ms / 1e3) / 1e9 if fill_ms > 0 else 0.0
+        value = total_nt * steps / elapsed
+        launches = stats["fill_launches"] * steps
+        achieved = stats["lattice_bytes"] * steps / (fill_ms / 1e3) / 1e9 if fill_ms > 0 else 0.0
         tier = dec.tier[:6]
         # HBM traffic of the fill kernel from PMC counters is collected in separate rocprofv3 passes (profiles/README.md)
         # and is NOT measured in this run: the field carries a recorded per-column figure only when a profile of this
         # configuration and kernel specialisation exists, with its source named; otherwise null.
         traffic, traffic_source = None, None
-        try:
-            src = os.path.join("profiles", "r2_traffic_config%d%s.json" % (args.config, args.variant if args.config == 3 else ""))
-            tj = json.load(open(os.path.join(ROOT, src)))
-            if tj.get("tier") == tier:
-                traffic = tj["hbm_bytes_per_column_corrected"] * stats["columns"] / max(stats["fill_launches"], 1)
-                traffic_source = "%s (separate rocprofv3 --pmc passes of this command, per column, scaled to this run's columns per launch)" % src
-        except (OSError, ValueError, KeyError):
-            pass
+        for rnd in ("r3", "r2"):
+            try:
+                src = os.path.join("profiles", "%s_traffic_config%d%s.json" % (rnd, config, variant if config == 3 else ""))
+                tj = json.load(open(os.path.join(ROOT, src)))
+                if tj.get("tier") == tier:
+                    traffic = tj["hbm_bytes_per_column_corrected"] * stats["columns"] / max(stats["fill_launches"], 1)
+                    traffic_source = "%s (separate rocprofv3 --pmc passes of this command, per column, scaled to this run's columns per launch)" % src
+                    break
+            except (OSError, ValueError, KeyError):
+                pass
         line = {
             "metric": "decoded nt/sec (whole node), Viterbi on composite FST",
-            "value": value, "unit": "nt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "value": value, "unit": "nt/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s, %d reads/GPU, --error-global, 1%% substitutions" % (wl["name"], n_reads),
                        "reads_per_gpu": n_reads, "total_nt": int(total_nt), "parallelism": "read-sharded x%d" % world,
-                       "inputs": "rank 0 scatter (RCCL)" if args.scatter else "generated per rank by read index"},
+                       "inputs": "rank 0 scatter (RCCL)" if scatter else "generated per rank by read index",
+                       # which fill kernel and row program served the run, and the tuning record that chose it
+                       "program": dec.tier},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "frac_whole_step": stats["lattice_bytes"] * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
+                         "frac_whole_step": stats["lattice_bytes"] * steps / elapsed / 1e9 / HBM_PEAK_GBS,
                          "kernel": "viterbi_fill_tiera" if tier in ("tier A", "tier C") else "viterbi_fill_kernel",
                          "tier": tier, "avg_launch_ms": fill_ms / max(launches, 1),
                          "algorithmic_bytes_per_launch": stats["lattice_bytes"] / max(stats["fill_launches"], 1),
                          "algorithmic_bytes_per_column": 8 * (dec.max_dup_len + 2) * dec.n_states,
                          "rounds_per_column": stats["rounds"] / max(stats["columns"], 1),
-                         "traceback_ms_per_step": tb_ms / args.steps},
+                         "traceback_ms_per_step": tb_ms / steps},
             "cpu_baseline": cpu,
         }
         line.update(extra)
-        print(json.dumps(line))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
     dec.close()
+    del d_sym, d_len, d_ll, d_st, d_bases
+    torch.cuda.empty_cache()
+    return line
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3, 4], help="index into BASELINE.json configs (default 2: the headline)")
+    ap.add_argument("--variant", default="a", choices=["a", "b"], help="config 3: a = water64.1*l4c4, b = hamming74*dropdot*water64.1*l4c4")
+    ap.add_argument("--reads", type=int, default=0, help="reads (config 4: pairs) per GPU; 0 = the configuration's default")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline time budget (0 = skip)")
+    ap.add_argument("--arena-gb", type=float, default=0.0, help="lattice arena per GPU (0 = the library's default, 60 %% of free HBM)")
+    ap.add_argument("--scatter", action="store_true", help="rank 0 makes every rank's reads and scatters them (RCCL) instead of per-rank generation")
+    ap.add_argument("--timed-only", action="store_true", help="skip the passes outside the timed region (PCIe-inclusive, single-read latency, CPU baseline, "
+                                                              "the other configurations): every launch of the run is then one of the timed steps (profiling)")
+    ap.add_argument("--no-other-configs", action="store_true", help="the headline run alone: skip the short passes of the other BASELINE configurations")
+    ap.add_argument("--options", default=None, help='dnas_model_create_ex options, e.g. "max_slots=690"')
+    ap.add_argument("--dump-decoded", default=None, help="rank 0 writes the gathered results (decoded string, log-likelihood bits, status per read, "
+                                                         "in read-index order) to this file as JSON (tests)")
+    args = ap.parse_args()
+
+    ctx = Ctx(args.gpus)
+    if args.config == 4:
+        import bench_fwdback
+        line = bench_fwdback.fwdback_line(ctx, args.reads, args.steps, args.warmup, args.cpu_seconds, args.timed_only)
+    else:
+        line = viterbi_line(ctx, args.config, args.variant, args.reads, args.steps, args.warmup, args.cpu_seconds, args.timed_only,
+                            args.scatter, args.arena_gb, args.options, args.dump_decoded)
+    # ---- the default run (the one the driver makes) also carries a short pass of every other BASELINE configuration, so that
+    # one driver-observed line holds them all: value, roofline, CPU baseline and parity count each.  One GPU only.
+    if ctx.world == 1 and args.config == 2 and not args.timed_only and not args.no_other_configs and not args.reads:
+        import bench_fwdback
+        others = {}
+        t_all = time.perf_counter()
+        for name, fn in (
+                ("configs[1]", lambda: viterbi_line(ctx, 1, "a", 64, 1, 1, 4.0)),
+                ("configs[3] (water64.1*l4c4)", lambda: viterbi_line(ctx, 3, "a", 2085, 1, 1, 4.0)),
+                ("configs[3] as written (hamming74*dropdot*water64.1*l4c4)", lambda: viterbi_line(ctx, 3, "b", 16, 1, 0, 4.0)),
+                ("configs[4]", lambda: bench_fwdback.fwdback_line(ctx, 0, 2, 1, 4.0, False))):
+            t1 = time.perf_counter()
+            try:
+                o = fn()
+                o["bench_seconds"] = time.perf_counter() - t1
+            except (Exception, SystemExit) as e:       # a failure here is reported, the headline line still goes out
+                o = {"error": "%s: %s" % (type(e).__name__, e)}
+            others[name] = o
+        line["other_configs"] = others
+        line["other_configs_seconds"] = time.perf_counter() - t_all
+    if ctx.rank == 0:
+        print(json.dumps(line))
+    ctx.close()
 
 
 if __name__ == "__main__":

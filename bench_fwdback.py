@@ -41,35 +41,16 @@ def _cpu_worker(job):
     return time.perf_counter() - t0, res
 
 
-def main(args):
-    import torch
-    import torch.distributed as dist
+def fwdback_line(ctx, n_pairs, steps, warmup, cpu_seconds, timed_only):
+    """BASELINE configs[4] on this run's GPUs -> the JSON line as a dict (rank 0; None elsewhere).  ctx: bench.Ctx."""
     import dnastore_amd as da
     from dnastore_amd import shard
     from oracle import oracle as O          # pair packing + CPU baseline (checker code, outside the timed region)
     import bench
+    torch, dist = ctx.torch, ctx.dist
+    rank, world, local_rank, coll_device = ctx.rank, ctx.world, ctx.local_rank, ctx.coll_device
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    backend = os.environ.get("DNAS_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank %= max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    coll_device = device if backend == "nccl" else torch.device("cpu")
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-
-    n_pairs = args.reads or 125000
+    n_pairs = n_pairs or 125000
     unique = 2000
     pairs = make_pairs(O, rank * n_pairs, n_pairs, unique)
     pk = O.pack_pairs(pairs)
@@ -81,19 +62,14 @@ def main(args):
         counts, ll, _ = fb.expectedCounts(params, want_pair_ll=False)
         return shard.allreduce_counts(counts, ll, world, coll_device)
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
+    fence = ctx.fence
+    for _ in range(warmup):
         step()
     fence()
     t0 = time.perf_counter()
     kernel_ms, lse_ops = 0.0, 0
     res = None
-    for _ in range(args.steps):
+    for _ in range(steps):
         res = step()
         st = fb.stats()
         kernel_ms += st["kernel_ms"]
@@ -108,31 +84,32 @@ def main(args):
     else:
         total_nt, total_pairs = float(nt), float(n_pairs)
 
+    line = None
     if rank == 0:
         st = fb.stats()
         cpu, extra = None, {}
-        if world == 1 and not args.timed_only:
+        if world == 1 and not timed_only:
             # the same shard through the one-call entry point (host arrays in, counts out: table + database uploaded per call)
             tp = time.perf_counter()
             c1, ll1, per1 = da.expectedCounts(params, pk, device=local_rank)
             extra["value_pcie_inclusive"] = nt / (time.perf_counter() - tp)
-            if args.cpu_seconds > 0:
+            if cpu_seconds > 0:
                 import multiprocessing as mp
                 O.build()
                 oparams = O.MutatorParams.from_cli()
                 t1 = time.perf_counter()
                 n1 = 0
-                while time.perf_counter() - t1 < args.cpu_seconds / 3.0 and n1 < n_pairs:
+                while time.perf_counter() - t1 < cpu_seconds / 3.0 and n1 < n_pairs:
                     O.expected_counts(oparams, pairs[n1:n1 + 50])
                     n1 += 50
                 dt1 = time.perf_counter() - t1
                 nt1 = int(sum(len(p[1]) for p in pairs[:n1]))
                 rate1 = nt1 / dt1
                 cores = bench.host_cores()
-                per_core = max(50, int(args.cpu_seconds * (n1 / dt1)))
+                per_core = max(50, int(cpu_seconds * (n1 / dt1)))
                 jobs = [(pairs[(c * per_core) % max(n_pairs - per_core, 1):][:per_core],) for c in range(cores)]
-                ctx = mp.get_context("spawn")
-                with ctx.Pool(len(jobs)) as pool:
+                mpctx = mp.get_context("spawn")
+                with mpctx.Pool(len(jobs)) as pool:
                     pool.map(_cpu_worker, [(j[0][:2],) for j in jobs])
                     t2 = time.perf_counter()
                     parts = pool.map(_cpu_worker, jobs)
@@ -150,7 +127,7 @@ def main(args):
                 if not np.allclose(gc, oc, rtol=1e-9, atol=1e-300):
                     raise SystemExit("PARITY FAILURE: counts differ from the oracle")
                 cpu["parity_checked_pairs"] = m
-        value = total_nt * args.steps / elapsed
+        value = total_nt * steps / elapsed
         # algorithmic HBM bytes per pair: the two sequences (1 B/nt), the guide columns (4 B per position) and
         # the 22+P doubles that come back
         P = len(params.pLen)
@@ -158,16 +135,16 @@ def main(args):
         alg_bytes = (in_nt + nt) + 4 * (in_nt + nt + 2 * n_pairs) + 8 * (22 + P) * n_pairs
         line = {
             "metric": "forward-backward E-step, read nt/sec (whole node)",
-            "value": value, "unit": "nt/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "value": value, "unit": "nt/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "configs[4]: %d pairs/GPU of a 256-nt original and its read (dup .01, sub .02, del .01), guide = true alignment, "
                                    "CLI default model (P = 6), %d distinct pairs tiled" % (n_pairs, min(unique, n_pairs)),
                        "pairs_per_gpu": n_pairs, "total_nt": int(total_nt), "parallelism": "pair-sharded x%d, counts all-reduced" % world},
-            "pairs_per_s": total_pairs * args.steps / elapsed,
-            "roofline": {"bound": "hbm", "achieved": alg_bytes * args.steps / (kernel_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg_bytes * args.steps / (kernel_ms / 1e3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
-                         "kernel": "fwdback_onchip_kernel", "avg_launch_ms": kernel_ms / args.steps,
+            "pairs_per_s": total_pairs * steps / elapsed,
+            "roofline": {"bound": "hbm", "achieved": alg_bytes * steps / (kernel_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg_bytes * steps / (kernel_ms / 1e3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
+                         "kernel": "fwdback_onchip_kernel", "avg_launch_ms": kernel_ms / steps,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "the DP cells live in LDS: the kernel is bound by the dependent log-sum-exp look-ups of a cell, not by HBM; "
                                  "lse_ops_per_s is its real rate",
@@ -176,8 +153,5 @@ def main(args):
             "cpu_baseline": cpu,
         }
         line.update(extra)
-        print(json.dumps(line))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
     fb.close()
+    return line

@@ -315,7 +315,7 @@ def format_event(ev):
         return "Substitution at %d: %s -> %s" % (pos, "ACGT"[(pay >> 2) & 3], "ACGT"[pay & 3])
     if kind == 2:
         return "Deletion between %d and %d: %s" % (pos - 1, pos, "ACGT"[pay & 3])
-    n = pay >> 16
+    n = pay >> 26
     return "Duplication at %d: %s" % (pos, "".join("ACGT"[(pay >> (2 * (n - 1 - i))) & 3] for i in range(n)))
 
 

@@ -308,7 +308,7 @@ static int decode_shard(const dnas_flat_model* fm, int device, const std::vector
     int rc = dnas_model_create(fm, device, 0, &model);
     if (rc != DNAS_OK) return fail(rc);
     *tier = dnas_model_tier(model);
-    if (events) (void)dnas_model_set_event_log(model, 1);
+    if (events && (rc = dnas_model_set_event_log(model, 1)) != DNAS_OK) return fail(rc);
     std::vector<char> sym(outOff.back());
     std::vector<uint32_t> len((size_t)n);
     std::vector<double> ll((size_t)n);

@@ -255,7 +255,7 @@ int main(int argc, char** argv) {
           else if (kind == 2) std::cerr << "Deletion between " << (long)pos - 1 << " and " << pos << ": " << base[pay & 3] << std::endl;
           else if (kind == 3) {
             std::string dup;
-            const unsigned cnt = pay >> 16;
+            const unsigned cnt = pay >> 26;
             for (unsigned q = 0; q < cnt; ++q) dup.push_back(base[(pay >> (2 * (cnt - 1 - q))) & 3]);
             std::cerr << "Duplication at " << pos << ": " << dup << std::endl;
           }

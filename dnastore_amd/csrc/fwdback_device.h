@@ -10,6 +10,7 @@ constexpr int kFbMaxCounts = 21 + kFbMaxLen;
 // on-chip kernel (fwdback_onchip.hip): sixteen lanes per pair, two pairs per work-group
 constexpr int kFbLanes = 16;
 constexpr int kFbPairsPerGroup = 2;
+constexpr size_t kFbOnchipLdsLimit = 150 * 1024;   // dynamic LDS a work-group of the on-chip kernel may ask for
 // doubles of LDS one pair needs there (Forward block, checkpoints, two Backward rows per lane + 1, substitution
 // counts, envelope bounds as int16)
 __host__ __device__ constexpr size_t fbOnchipPairDoubles(int maxInLen) {

@@ -73,7 +73,7 @@ struct dnas_fb {
   double *dCounts = nullptr, *dLL = nullptr, *dPartial = nullptr;
   unsigned long long* dLseOps = nullptr;
   // per guide mode (0: the envelope is maxDistance = P wide, 1: strict) and P: which kernel takes which pair
-  struct Route { int P = -1; std::vector<int64_t> onchip, streaming; std::vector<int64_t> cells; std::vector<int> width;
+  struct Route { int P = -1; int maxInOnchip = 0; std::vector<int64_t> onchip, streaming; std::vector<int64_t> cells; std::vector<int> width;
                  int64_t* dOnchip = nullptr; int64_t* dStreaming = nullptr; };
   Route route[2];
   // streaming kernel arenas
@@ -227,6 +227,11 @@ extern "C" int dnas_fb_estep(dnas_fb* h, const dnas_mutator_params* p, int stric
     rt.width.assign((size_t)n_pairs, 1);
     const int Dm = a.maxDistance;
     const bool forceStreaming = getenv("DNAS_FB_STREAMING") != nullptr;
+    // the on-chip kernel keeps a pair's checkpoints and envelope bounds in LDS: a pair whose input is too long for that goes
+    // to the streaming kernel like the pairs with wide envelope rows (never fail the call for it)
+    int longestOnchip = 0;
+    while (kFbPairsPerGroup * fbOnchipPairDoubles(longestOnchip + 64) * sizeof(double) <= kFbOnchipLdsLimit) longestOnchip += 64;
+    rt.maxInOnchip = 0;
     for (int64_t i = 0; i < n_pairs; ++i) {
       const int64_t inLen = h->inOff[i + 1] - h->inOff[i], outLen = h->outOff[i + 1] - h->outOff[i];
       const int32_t* ci = h->ci.data() + h->ciOff[i];
@@ -242,7 +247,9 @@ extern "C" int dnas_fb_estep(dnas_fb* h, const dnas_mutator_params* p, int stric
       }
       rt.cells[(size_t)i] = std::max<int64_t>(tot, 1);
       rt.width[(size_t)i] = w;
-      (w <= kFbLanes && P <= 8 && !forceStreaming ? rt.onchip : rt.streaming).push_back(i);
+      const bool chip = w <= kFbLanes && P <= 8 && inLen <= longestOnchip && !forceStreaming;
+      (chip ? rt.onchip : rt.streaming).push_back(i);
+      if (chip) rt.maxInOnchip = std::max<int>(rt.maxInOnchip, (int)inLen);
     }
     auto put = [&](const std::vector<int64_t>& v, int64_t** d) -> hipError_t {
       hipError_t e = hipMalloc((void**)d, std::max<size_t>(v.size(), 1) * sizeof(int64_t));
@@ -265,12 +272,11 @@ extern "C" int dnas_fb_estep(dnas_fb* h, const dnas_mutator_params* p, int stric
 
   // ---- on-chip kernel: two pairs per work-group, everything in LDS
   if (!rt.onchip.empty()) {
-    const size_t lds = kFbPairsPerGroup * fbOnchipPairDoubles(h->maxInLen) * sizeof(double);
-    if (lds > 150 * 1024) return dnas::fail(DNAS_E_UNSUPPORTED, "sequences too long for the on-chip forward-backward kernel");
+    const size_t lds = kFbPairsPerGroup * fbOnchipPairDoubles(rt.maxInOnchip) * sizeof(double);   // <= kFbOnchipLdsLimit by the routing
     const int64_t nL = (int64_t)rt.onchip.size();
     hipLaunchKernelGGL(fwdback_onchip_kernel, dim3((unsigned)((nL + kFbPairsPerGroup - 1) / kFbPairsPerGroup)), dim3(kFbLanes * kFbPairsPerGroup),
                        lds, h->stream, a, h->dIn, h->dInOff, h->dOut, h->dOutOff, h->dCi, h->dCiOff, h->dCo, h->dCoOff, h->dTab, rt.dOnchip, nL,
-                       h->dCounts, h->dLL, h->maxInLen, h->dLseOps);
+                       h->dCounts, h->dLL, rt.maxInOnchip, h->dLseOps);
     HIP_TRY(hipGetLastError());
   }
   // ---- streaming kernel for the rest: the interleaved Forward arena holds cellCap cells for each of B pairs

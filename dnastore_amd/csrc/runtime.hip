@@ -1151,6 +1151,8 @@ extern "C" const char* dnas_model_tier(const dnas_model* m) { return m ? m->tier
 
 extern "C" int dnas_model_set_event_log(dnas_model* m, int on) {
   if (!m) return dnas::fail(DNAS_E_INVALID, "null model");
+  if (on && m->dm.D > 13)     // a duplication event carries its bases in 26 bits (viterbi_kernels.hip)
+    return dnas::fail(DNAS_E_UNSUPPORTED, "the traceback event log holds at most 13 duplicated bases per event; this model has " + std::to_string(m->dm.D) + " duplication lanes");
   m->eventLog = on != 0;
   return DNAS_OK;
 }

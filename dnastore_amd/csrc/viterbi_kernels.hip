@@ -298,7 +298,7 @@ viterbi_traceback_kernel(DevModel m, const uint8_t* __restrict__ bases, const ui
   long n = 0;
   // optional log of what the traceback found (the reference's level-3 messages, viterbi.cpp:266-293), in the order
   // it walks (from the end of the read): type << 62 | pos << 32 | payload.  1 substitution at pos: emitted base << 2 |
-  // read base; 2 deletion between pos-1 and pos: the deleted base; 3 duplication at pos: count << 16 | bases (2 bits each)
+  // read base; 2 deletion between pos-1 and pos: the deleted base; 3 duplication at pos: count << 26 | bases (2 bits each, at most 13: kEventDupBases)
   unsigned long long* ev = events ? events + evOff[read] : nullptr;
   const long evCap = events ? (long)(evOff[read + 1] - evOff[read]) : 0;
   long nEv = 0;
@@ -418,7 +418,7 @@ viterbi_traceback_kernel(DevModel m, const uint8_t* __restrict__ bases, const ui
         if (ev && bestMut == 0) {        // viterbi.cpp:288-293: the duplicated bases, outermost first
           unsigned bases = 0;
           for (int q = k; q >= 0; --q) bases = (bases << 2) | ctx[q];
-          EVENT(3, pos, ((unsigned)(k + 1) << 16) | bases)
+          EVENT(3, pos, ((unsigned)(k + 1) << 26) | (bases & 0x3ffffffu))
         }
       }
       CHECK_BEST();
@@ -614,7 +614,7 @@ viterbi_traceback_wave_kernel(DevModel m, const uint8_t* __restrict__ bases, con
         if (ev && bMut == 0) {        // viterbi.cpp:288-293: the duplicated bases, outermost first
           unsigned basesDup = 0;
           for (int q = k; q >= 0; --q) basesDup = (basesDup << 2) | (unsigned)__shfl(meta, 8 + q, 64);
-          WEVENT(3, pos, ((unsigned)(k + 1) << 16) | basesDup)
+          WEVENT(3, pos, ((unsigned)(k + 1) << 26) | (basesDup & 0x3ffffffu))
         }
       }
       W_CHECK();

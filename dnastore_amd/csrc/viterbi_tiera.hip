@@ -80,6 +80,15 @@ __device__ __forceinline__ void static_for(F&& f) {
 #ifndef DNAS_GSROWS
 #define DNAS_GSROWS DNAS_GROWS
 #endif
+#ifndef DNAS_POLLS
+#define DNAS_POLLS 1   // tier C: how often a sweep looks into the inbox (the polls are spread evenly over the rows)
+#endif
+#ifndef DNAS_POLL_SPLIT
+#define DNAS_POLL_SPLIT 0
+#endif
+#ifndef DNAS_POLL_LAG
+#define DNAS_POLL_LAG 1   // ... and a poll folds what the poll DNAS_POLL_LAG polls before it loaded (DNAS_POLLS is a multiple of it)
+#endif
 
 // kernel-argument block (mirrors runtime.hip TierAArgs)
 struct TierAArgs {
@@ -134,16 +143,38 @@ __device__ __forceinline__ void ldsMax(char* base, unsigned byteOff, double v) {
 __device__ __forceinline__ double ldsMaxRtn(char* base, unsigned byteOff, double v) {   // returns what the cell held
   return __hip_atomic_fetch_max(reinterpret_cast<double*>(base + byteOff), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-// exchange buffer: 8-byte agent-scope atomics on both sides (the offers are performed at the memory
-// side, the owner's loads and clears bypass this CU's L1), so a hand-over needs no fence
-__device__ __forceinline__ void xMax(char* base, unsigned byteOff, double v) {
-  __hip_atomic_fetch_max(reinterpret_cast<double*>(base + byteOff), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// Global memory is addressed the buffer way -- a uniform base in scalar registers (a resource descriptor), a 32-bit
+// per-lane byte offset and a uniform byte offset: the address arithmetic of the tables, the lattice columns and the
+// exchange buffer runs on the scalar unit and no 64-bit pointer sits in vector registers (as global_* accesses the
+// 28-row program held 39 hoisted pointers and spilled 55 registers).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ rsrc_t makeRsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)0xffffffffu, 0x00020000);   // raw buffer, no range to speak of
 }
-__device__ __forceinline__ double xLoad(const char* base, unsigned byteOff) {
-  return __hip_atomic_load(reinterpret_cast<const double*>(base + byteOff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+constexpr int kAuxNt = 2, kAuxSc1 = 16;   // cache policy bits of a buffer access (gfx940+: bit 0 sc0, bit 1 nt, bit 4 sc1)
+__device__ __forceinline__ unsigned bufLoadU32(rsrc_t r, unsigned laneOff, unsigned uniOff) {
+  return __builtin_amdgcn_raw_buffer_load_b32(r, (int)laneOff, (int)uniOff, 0);
 }
-__device__ __forceinline__ void xStore(char* base, unsigned byteOff, double v) {
-  __hip_atomic_store(reinterpret_cast<double*>(base + byteOff), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// exchange buffer: 8-byte agent-scope accesses on both sides (the offers are atomics performed at the memory side, the
+// owner's loads and clears carry sc1 and bypass this CU's L1), so a hand-over needs no fence
+// (the atomic is written out: not every hiprtc this library meets knows the builtin of its buffer form; desc = the four
+//  words of the buffer's descriptor)
+__device__ __forceinline__ u32x4 makeDesc(const void* base) {
+  const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+  u32x4 d;
+  d.x = (unsigned)b; d.y = (unsigned)(b >> 32); d.z = 0xffffffffu; d.w = 0x00020000u;
+  return d;
+}
+__device__ __forceinline__ void xMax(u32x4 desc, unsigned laneOff, unsigned uniOff, double v) {
+  asm volatile("buffer_atomic_max_f64 %0, %1, %2, %3 offen" : : "v"(v), "v"(laneOff), "s"(desc), "s"(uniOff) : "memory");
+}
+__device__ __forceinline__ double xLoad(rsrc_t r, unsigned laneOff, unsigned uniOff) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)laneOff, (int)uniOff, kAuxSc1));
+}
+__device__ __forceinline__ void xStore(rsrc_t r, unsigned laneOff, unsigned uniOff, double v) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)laneOff, (int)uniOff, kAuxSc1);
 }
 __device__ __forceinline__ unsigned wLoad(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -209,7 +240,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
   // walks the reads cluster, cluster + nClusters, ...  Blocks b and b + 8 land on the same XCD (observed
   // dispatch order, speed only): the members of a cluster are 8 blocks apart.
   int member = 0, rFirst = (int)blockIdx.x, rStep = 1, rEnd = (int)blockIdx.x + 1;
-  char* xB = nullptr;          // this cluster's exchange buffer (bytes)
+  const double* xBase = xbuf;  // this cluster's exchange buffer
   unsigned* SY = nullptr;      // this cluster's sync block
   if constexpr (G_ > 1) {
     const int b = (int)blockIdx.x, q = b >> 3;
@@ -217,7 +248,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
     const int cluster = (q / G_) * 8 + (b & 7);
     if (cluster >= nClusters) return;
     rFirst = cluster; rStep = nClusters; rEnd = nReads;
-    xB = reinterpret_cast<char*>(xbuf + (size_t)cluster * kXStride);
+    xBase = xbuf + (size_t)cluster * kXStride;
     SY = syncWords + (size_t)cluster * 64;
     entTab += (size_t)member * kEntries * T;
     metaTab += (size_t)member * K * T;
@@ -229,21 +260,24 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
     }
   }
   constexpr unsigned kXA = 0u, kXBd = kCells * 8u, kXBs = 2u * kCells * 8u, kXRed = 3u * kCells * 8u;
-  // own inbox cells: slot r*T + tid of this member
-#define X_OWN(r) ((unsigned)(((unsigned)member * DNAS_GROWS + (unsigned)(r)) * T + (unsigned)tid) * 8u)
+  const u32x4 xBd = makeDesc(xBase);
+  const rsrc_t xB = makeRsrc(xBase), rEnt = makeRsrc(entTab), rMeta = makeRsrc(metaTab), rFold = makeRsrc(foldTab);
+  const unsigned tid4 = (unsigned)tid * 4u, tid8 = (unsigned)tid * 8u, tid16 = (unsigned)tid * 16u;
+  // own inbox cells: slot r*T + tid of this member -- array base + X_OWN_U(r) uniform, tid8 per lane
+#define X_OWN_U(r) ((unsigned)(((unsigned)member * DNAS_GROWS + (unsigned)(r)) * T) * 8u)
   // where slot r*T + tid folds into: byte addresses of the state's DC and SC cells (0 / 0x7fff8: none)
   constexpr int R_ = DNAS_GROWS > 0 ? DNAS_GROWS : 1;
   unsigned FT[R_];
-  if constexpr (G_ > 1) static_for<0, DNAS_GROWS>([&](auto rc) { FT[rc.value] = foldTab[(size_t)rc.value * T + tid]; });
+  if constexpr (G_ > 1) static_for<0, DNAS_GROWS>([&](auto rc) { FT[rc.value] = bufLoadU32(rFold, tid4, (unsigned)rc.value * T * 4u); });
 #define FOLD_DC(f) (((f) & 0xffffu) << 3)
 #define FOLD_SC(f) (((f) >> 16) << 3)
 #define FOLD_HAS_SC(f) ((f) != 0u && ((f) >> 16) != 0xffffu)
 
   // the out-edge entries: in registers for the whole launch
   unsigned E[kEntries];
-  static_for<0, kEntries>([&](auto m) { E[m.value] = entTab[(size_t)m.value * T + tid]; });
+  static_for<0, kEntries>([&](auto m) { E[m.value] = bufLoadU32(rEnt, tid4, (unsigned)m.value * T * 4u); });
 #define ENTRY(i) opaque(E[i])
-#define META(k) (metaTab[(size_t)(k) * T + tid])
+#define META(k) bufLoadU32(rMeta, tid4, (unsigned)(k) * T * 4u)
   // score of an edge by class: class 0 is 0.0 (adding it is the identity on every value that occurs)
   auto withScore = [&](double v, unsigned cls) -> double {
     if constexpr (DNAS_NCLS <= 1) return v;
@@ -281,30 +315,34 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
 
   // The S and D lanes of column p leave for HBM from the registers, 16 bytes per lane (rows 2m and
   // 2m+1 of a thread are lattice neighbours).
+  // (column p of this member starts at latM + p * lanes * NS doubles: a descriptor per column; the lane and the pair are
+  //  the uniform offset, 16 * tid the lane's)
+#define COL_RSRC(p) makeRsrc(latM + (size_t)(p) * lanes * NS)
+#define PAIR_OFF(lane, m2) ((unsigned)(((unsigned)(lane) * NS + (unsigned)(m2) * 2u * T) * 8u))
 #define STORE_LANE(p, lane, REG)                                                                 \
   {                                                                                              \
-    double* const colp = latM + ((size_t)(p) * lanes + (lane)) * NS;                             \
+    const rsrc_t colp = COL_RSRC(p);                                                             \
     static_for<0, K / 2>([&](auto mc) {                                                          \
       constexpr int m2 = mc.value;                                                               \
       if (pairValid & (1u << m2)) {                                                              \
         dbl2 v2;                                                                                 \
         v2.x = REG[2 * m2]; v2.y = REG[2 * m2 + 1];                                              \
-        if ((lane) == 1 && DNAS_NT_D)   /* the D lane is not read again by this kernel */          \
-          __builtin_nontemporal_store(v2, reinterpret_cast<dbl2*>(colp + (size_t)m2 * 2 * T) + tid); \
-        else                                                                                     \
-          reinterpret_cast<dbl2*>(colp + (size_t)m2 * 2 * T)[tid] = v2;                          \
+        /* the D lane is not read again by this kernel: past the caches */                       \
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v2), colp, (int)tid16, (int)PAIR_OFF(lane, m2), \
+                                               ((lane) == 1 && DNAS_NT_D) ? kAuxNt : 0);         \
       }                                                                                          \
     });                                                                                          \
   }
   // ... and come back from it when a read is resumed at a checkpoint (bounded-memory decode, runtime.hip)
 #define LOAD_LANE(p, lane, REG)                                                                  \
   {                                                                                              \
-    const double* const colp = latM + ((size_t)(p) * lanes + (lane)) * NS;                       \
+    const rsrc_t colp = COL_RSRC(p);                                                             \
     static_for<0, K / 2>([&](auto mc) {                                                          \
       constexpr int m2 = mc.value;                                                               \
       dbl2 v2;                                                                                   \
       v2.x = kNegInf; v2.y = kNegInf;                                                            \
-      if (pairValid & (1u << m2)) v2 = reinterpret_cast<const dbl2*>(colp + (size_t)m2 * 2 * T)[tid]; \
+      if (pairValid & (1u << m2))                                                                \
+        v2 = __builtin_bit_cast(dbl2, __builtin_amdgcn_raw_buffer_load_b128(colp, (int)tid16, (int)PAIR_OFF(lane, m2), 0)); \
       REG[2 * m2] = v2.x; REG[2 * m2 + 1] = v2.y;                                                \
     });                                                                                          \
   }
@@ -351,7 +389,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
   double* const latM = lat + (size_t)member * NSm;   // this member's slots of a column
   const unsigned redOff = kXRed + (unsigned)(((r - rFirst) / rStep) & 1) * 8u;
   if constexpr (G_ > 1) {
-    if (member == 0 && tid == 0) xStore(xB, redOff, kNegInf);   // this read's reduction cell (last used two reads ago)
+    if (member == 0 && tid == 0) xStore(xB, 0u, redOff, kNegInf);   // this read's reduction cell (last used two reads ago)
   }
 
   // Bounded-memory decode: this launch fills columns c0 .. c1 of the read only.  A segment that stops short of the read's
@@ -372,7 +410,6 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
 
   bool earlyOffered = false;     // the offers of the column about to start have been made already (phase C of the column before)
   for (int pos = c0; pos <= c1 && !aborted; ++pos) {
-    double* const col = latM + (size_t)pos * lanes * NS;
     const int x = pos > 0 ? seq[pos - 1] : 0;
     ++colSeq;
     if constexpr (G_ > 1) tStart = __builtin_amdgcn_s_memrealtime();
@@ -396,7 +433,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
             if constexpr (kRows[k].gOut != 0) {
               if (kRows[k].gOut == 1 ? ENT_VALID(en) : ENT_GLOBAL(en)) {
                 if (kRows[k].kind == 1 || !ENT_GNULL(en))
-                  xMax(xB, kXA + ENT_GCELL(en), (withScoreRow(kc, S[k], en) + a.noGap) + ldsRead(ldsB, subRow + ENT_GBASE32(en)));
+                  xMax(xBd, ENT_GCELL(en), kXA, (withScoreRow(kc, S[k], en) + a.noGap) + ldsRead(ldsB, subRow + ENT_GBASE32(en)));
                 return;
               }
               if constexpr (kRows[k].gOut == 1) return;
@@ -426,13 +463,13 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
         double xa[R_];
         static_for<0, DNAS_GROWS>([&](auto rc) {   // all loads in flight together
           xa[rc.value] = kNegInf;
-          if (FT[rc.value]) xa[rc.value] = xLoad(xB, kXA + X_OWN(rc.value));
+          if (FT[rc.value]) xa[rc.value] = xLoad(xB, tid8, kXA + X_OWN_U(rc.value));
         });
         static_for<0, DNAS_GROWS>([&](auto rc) {
           constexpr int r = rc.value;
           if (xa[r] > kNegInf) {
             ldsMax(ldsB, FOLD_DC(FT[r]), xa[r]);
-            xStore(xB, kXA + X_OWN(r), kNegInf);      // nobody offers here again before the next column's barrier
+            xStore(xB, tid8, kXA + X_OWN_U(r), kNegInf);      // nobody offers here again before the next column's barrier
           }
         });
         __syncthreads();
@@ -481,26 +518,60 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
       unsigned geSeen = geBase;
       bool pendingBump = false;
       xDirty = 0;
+      // The inbox is looked into DNAS_POLLS times per sweep.  A poll folds what the poll DNAS_POLL_LAG polls BEFORE it loaded
+      // (those loads have arrived by now: a load of a cell that another member's atomic has just touched comes from the
+      // memory side, about two microseconds) into the LDS accumulators of the states behind the slots, and loads the slots
+      // again: what another member offers reaches its state's row within half a sweep instead of a sweep and a half
+      // (tools/cluster_sim.py: 13-14 sweeps per column instead of 18.6 on the 46 670-state machine).
+      constexpr int kPollStride = (K + DNAS_POLLS - 1) / DNAS_POLLS, kLag = DNAS_POLL_LAG;
+      static_assert(DNAS_POLLS % DNAS_POLL_LAG == 0, "the polls of a sweep take the register sets in turn");
+      constexpr int RS_ = DNAS_GSROWS > 0 ? DNAS_GSROWS : 1;
+      double xd[kLag][R_], xs[kLag][RS_], lastD[R_], lastS[RS_];   // last*: what has been folded (the cells were cleared in phase C)
+      static_for<0, R_>([&](auto rc) { lastD[rc.value] = kNegInf; });
+      static_for<0, RS_>([&](auto rc) { lastS[rc.value] = kNegInf; });
+      static_for<0, kLag>([&](auto lc) {
+        static_for<0, R_>([&](auto rc) { xd[lc.value][rc.value] = kNegInf; });
+        static_for<0, RS_>([&](auto rc) { xs[lc.value][rc.value] = kNegInf; });
+      });
       for (;;) {
         asm volatile("" ::: "memory");   // other waves write LDS between sweeps: reload everything
         const unsigned e0 = __hip_atomic_load(epochL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (ln == 0) __hip_atomic_store(&idleL[wv], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         int changed = 0, sentX = 0;
         unsigned geNow = geSeen;
-        // the inbox is folded at the end of the sweep: its cells are loaded now and have arrived by then
-        double xd[R_], xs[DNAS_GSROWS > 0 ? DNAS_GSROWS : 1];
-        if constexpr (G_ > 1) {
-          if (wv == 0) geNow = wLoad(&SY[0]);
+        if constexpr (G_ > 1) { if (wv == 0) geNow = wLoad(&SY[0]); }
+        auto loadInbox = [&](auto setc) {
+          constexpr int q = setc.value;
           static_for<0, DNAS_GROWS>([&](auto rc) {
             constexpr int r = rc.value;
-            xd[r] = kNegInf;
-            if (FT[r]) xd[r] = xLoad(xB, kXBd + X_OWN(r));
-            if constexpr (r < DNAS_GSROWS) {
-              xs[r] = kNegInf;
-              if (FOLD_HAS_SC(FT[r])) xs[r] = xLoad(xB, kXBs + X_OWN(r));
-            }
+            xd[q][r] = xLoad(xB, tid8, kXBd + X_OWN_U(r));
+            if constexpr (r < DNAS_GSROWS) xs[q][r] = xLoad(xB, tid8, kXBs + X_OWN_U(r));
           });
-        }
+        };
+        auto foldInbox = [&](auto setc) {
+          constexpr int q = setc.value;
+          // An inbox cell only grows within a column, and lastD / lastS hold what this thread has folded of its cells: a poll that
+          // finds nothing new -- most do -- costs the loads and one comparison per cell.  Unused slots (FT == 0) are real cells
+          // that nobody offers into: they read -inf for ever, so the loads need no mask.  A cell that raises its state's
+          // accumulator counts like an offer of this wave.
+          bool anyNew = false;
+          static_for<0, DNAS_GROWS>([&](auto rc) {
+            constexpr int r = rc.value;
+            anyNew = anyNew || xd[q][r] != lastD[r];
+            if constexpr (r < DNAS_GSROWS) anyNew = anyNew || xs[q][r] != lastS[r];
+          });
+          if (__any(anyNew)) {
+            static_for<0, DNAS_GROWS>([&](auto rc) {
+              constexpr int r = rc.value;
+              if (xd[q][r] != lastD[r]) { lastD[r] = xd[q][r]; if (ldsMaxRtn(ldsB, FOLD_DC(FT[r]), xd[q][r]) < xd[q][r]) changed = 1; }
+              if constexpr (r < DNAS_GSROWS) {
+                if (xs[q][r] != lastS[r]) { lastS[r] = xs[q][r]; if (ldsMaxRtn(ldsB, FOLD_SC(FT[r]), xs[q][r]) < xs[q][r]) changed = 1; }
+              }
+            });
+          }
+        };
+        // DNAS_POLL_SPLIT: one poll per sweep, loaded behind the last row and folded in front of the first row of the next sweep
+        auto pollInbox = [&](auto setc) { foldInbox(setc); if constexpr (!DNAS_POLL_SPLIT) loadInbox(setc); };
         // One row of the sweep; dIn / scIn: its accumulators as read.
         auto rowEval = [&](auto kc, double dIn, double scIn) {
           constexpr int k = kc.value, o = rowOffset(k);
@@ -527,10 +598,10 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
                   if (kRows[k].gOut == 1 || ENT_GLOBAL(en)) {
                     sentX = 1;
                     if (kRows[k].kind == 1 || (kRows[k].kind != 2 && !ENT_GNULL(en))) {
-                      xMax(xB, kXBd + ENT_GCELL(en), withScoreRow(kc, xv, en));
+                      xMax(xBd, ENT_GCELL(en), kXBd, withScoreRow(kc, xv, en));
                     } else {                                           // viterbi.cpp:137-151
-                      xMax(xB, kXBd + ENT_GCELL(en), withScoreRow(kc, d, en));
-                      xMax(xB, kXBs + ENT_GCELL(en), withScoreRow(kc, s, en));
+                      xMax(xBd, ENT_GCELL(en), kXBd, withScoreRow(kc, d, en));
+                      xMax(xBd, ENT_GCELL(en), kXBs, withScoreRow(kc, s, en));
                     }
                     return;
                   }
@@ -554,6 +625,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
         };
         static_for<0, K>([&](auto kc) {
           constexpr int k = kc.value;
+          if constexpr (G_ > 1 && k % kPollStride == 0) pollInbox(IntC<(k / kPollStride) % kLag>{});
           if constexpr (!rowLive(k)) return;
           double sc = kNegInf;
           const double d = ldsRead(ldsB, DC_OWN(k));
@@ -561,17 +633,10 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
           rowEval(kc, d, sc);
         });
         ++rounds;
+        if constexpr (G_ > 1 && DNAS_POLL_SPLIT) loadInbox(IntC<0>{});
         if constexpr (G_ > 1) {
-          // fold the inbox: a cell that raises its state's LDS accumulator counts like an offer of this wave
-          static_for<0, DNAS_GROWS>([&](auto rc) {
-            constexpr int r = rc.value;
-            if (xd[r] > kNegInf) { xDirty |= 1u << r; if (ldsMaxRtn(ldsB, FOLD_DC(FT[r]), xd[r]) < xd[r]) changed = 1; }
-            if constexpr (r < DNAS_GSROWS) {
-              if (xs[r] > kNegInf) { xDirty |= 0x100u << r; if (ldsMaxRtn(ldsB, FOLD_SC(FT[r]), xs[r]) < xs[r]) changed = 1; }
-            }
-          });
-          // the loads above were issued after the exchange offers of the previous sweep and have returned, so those
-          // offers have completed (a wave's memory operations complete in order): GE may say so now
+          // the exchange offers of the sweep before have had a sweep to complete: GE may say so now (the wait is for the
+          // stragglers, and for this sweep's own offers)
           if (pendingBump) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (ln == 0) __hip_atomic_fetch_add(&SY[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -651,6 +716,12 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
         }
         if (done) break;
       }
+      // the inbox cells that were offered into (every offer was folded: the fixpoint was agreed) are cleared in phase C
+      static_for<0, DNAS_GROWS>([&](auto rc) {
+        constexpr int r = rc.value;
+        if (lastD[r] > kNegInf) xDirty |= 1u << r;
+        if constexpr (r < DNAS_GSROWS) { if (lastS[r] > kNegInf) xDirty |= 0x100u << r; }
+      });
       __syncthreads();   // all waves are out of the sweeps before phase C clears the accumulators
       if constexpr (G_ > 1) {
         aborted = *abortL != 0u;
@@ -679,8 +750,8 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
         // the last sweep; nobody offers into XB again before the next column's barrier)
         static_for<0, DNAS_GROWS>([&](auto rc) {
           constexpr int r = rc.value;
-          if (xDirty & (1u << r)) xStore(xB, kXBd + X_OWN(r), kNegInf);
-          if (xDirty & (0x100u << r)) xStore(xB, kXBs + X_OWN(r), kNegInf);
+          if (xDirty & (1u << r)) xStore(xB, tid8, kXBd + X_OWN_U(r), kNegInf);
+          if (xDirty & (0x100u << r)) xStore(xB, tid8, kXBs + X_OWN_U(r), kNegInf);
         });
       }
       const int xn = pos < L ? seq[pos] : 0;
@@ -708,7 +779,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
         constexpr int k0 = gc.value * G, k1 = (k0 + G < K) ? k0 + G : K;
         unsigned metaG[G];
         static_for<k0, k1>([&](auto kc) {   // (address rebuilt here: 14 hoisted pointers would cost 28 registers)
-          metaG[kc.value - k0] = rowLive(kc.value) ? metaTab[(size_t)kc.value * T + opaque((unsigned)tid)] : 0u;
+          metaG[kc.value - k0] = rowLive(kc.value) ? META(kc.value) : 0u;
         });
         double sh[G][D_ > 1 ? D_ - 1 : 1];
         static_for<1, D_>([&](auto ic) {
@@ -717,9 +788,9 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
             static_for<k0 / 2, k1 / 2>([&](auto mc) {
               constexpr int m2 = mc.value;
               if constexpr (!rowLive(2 * m2) && !rowLive(2 * m2 + 1)) return;
-              const dbl2* const hp = reinterpret_cast<const dbl2*>(col - (size_t)i * lanes * NS + (size_t)m2 * 2 * T) + tid;
               // the oldest column is read for the last time: stream it past the caches
-              const dbl2 v2 = (DNAS_NT_H && i >= D_ - DNAS_NT_H) ? __builtin_nontemporal_load(hp) : *hp;
+              const dbl2 v2 = __builtin_bit_cast(dbl2, __builtin_amdgcn_raw_buffer_load_b128(COL_RSRC(pos - i), (int)tid16, (int)PAIR_OFF(0, m2),
+                                                                                              (DNAS_NT_H && i >= D_ - DNAS_NT_H) ? kAuxNt : 0));
               sh[2 * m2 - k0][i - 1] = v2.x;
               sh[2 * m2 + 1 - k0][i - 1] = v2.y;
             });
@@ -807,13 +878,13 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
   __syncthreads();
   if (tid == 0) {
     for (int w = 1; w < T / 64; ++w) best = dmax(best, red[w]);
-    if constexpr (G_ > 1) xMax(xB, redOff, best);
+    if constexpr (G_ > 1) xMax(xBd, 0u, redOff, best);
     else { red[0] = best; outLoglike[read] = best; }
   }
   if constexpr (G_ > 1) {
     clusterBarrier();          // every member's best has landed (and the last column's accumulators are clear)
     if (aborted) break;
-    if (tid == 0) red[0] = xLoad(xB, redOff);
+    if (tid == 0) red[0] = xLoad(xB, 0u, redOff);
   }
   __syncthreads();
   {

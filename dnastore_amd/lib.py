@@ -9,7 +9,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdnastore_amd.so")
+# DNAS_LIBRARY: another build of the same library (tools/run_asan.sh: the sanitizer build under dnastore_amd/asan/)
+LIB_PATH = os.environ.get("DNAS_LIBRARY") or os.path.join(_HERE, "libdnastore_amd.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "dnastore_amd.h")
 
 DNAS_OK = 0

@@ -71,7 +71,7 @@ def gather_results(sym, out_len, loglike, status, world, rank):
     shape = torch.tensor([k, cap, -cap if k else -(1 << 40)], dtype=torch.int64, device=sym.device)
     dist.all_reduce(shape, op=dist.ReduceOp.MAX)
     kmax, capmax, capmin = int(shape[0]), int(shape[1]), -int(shape[2])
-    if k and (cap != capmax or capmin != capmax):
+    if capmin != capmax and kmax > 0:      # (global values: every rank raises, none is left waiting in a collective)
         raise ValueError("gather_results: the output capacity per read differs across ranks")
     cap = capmax
 

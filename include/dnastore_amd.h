@@ -308,7 +308,8 @@ typedef struct dnas_decoded dnas_decoded; /* vguard<FastSeq> result of decodeFas
  * messages, viterbi.cpp:266-293): per read a list of 64-bit events in the order the traceback met them,
  * type << 62 | position << 32 | payload -- 1: substitution at position, payload = emitted base << 2 | read base;
  * 2: deletion between position-1 and position, payload = the deleted base; 3: duplication at position, payload =
- * count << 16 | the duplicated bases, 2 bits each, first one in the highest bits. */
+ * count << 26 | the duplicated bases, 2 bits each, first one in the highest bits (a model with more than 13 duplication
+ * lanes cannot log them: dnas_model_set_event_log then returns DNAS_E_UNSUPPORTED). */
 int dnas_decode_fastseqs(const char *fasta_path, const dnas_machine *m, const dnas_mutator_params *p,
                          int device_id, dnas_decoded **out);
 int dnas_decode_fastseqs_ex(const char *fasta_path, const dnas_machine *m, const dnas_mutator_params *p,

@@ -26,6 +26,8 @@ ERRORS = {1: "context mismatch", 2: "not a DNA-outputting machine", 3: "transduc
 
 def build(force=False):
     """Compile oracle/liboracle.so with gcc (oracle/Makefile)."""
+    if os.environ.get("DNAS_ORACLE_LIBRARY"):      # another build of the oracle (tools/run_asan.sh: the sanitizer build)
+        return os.environ["DNAS_ORACLE_LIBRARY"]
     so = os.path.join(_HERE, "liboracle.so")
     srcs = [os.path.join(_HERE, f) for f in ("viterbi_oracle.c", "fwdback_oracle.c", "Makefile")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs if os.path.exists(s)):
@@ -36,7 +38,7 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "liboracle.so")
+        so = os.environ.get("DNAS_ORACLE_LIBRARY") or os.path.join(_HERE, "liboracle.so")
         if not os.path.exists(so):
             build()
         _LIB = ctypes.CDLL(so)

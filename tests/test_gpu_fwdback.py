@@ -117,3 +117,20 @@ def test_onchip_and_streaming_kernels_agree(oracle_mod, monkeypatch):
     assert fb.stats()["pairs_onchip"] == 0
     assert np.array_equal(pers, per) and np.allclose(cs, counts, rtol=1e-11, atol=1e-300)
     fb.close()
+
+
+def test_one_long_pair_does_not_fail_the_database(oracle_mod):
+    """A database with one input far longer than the on-chip kernel's LDS can hold (its checkpoints grow with the input) beside
+    ordinary pairs: the long pair goes to the streaming kernel, the call succeeds and matches the oracle pair by pair."""
+    import dnastore_amd as da
+    from synth import synthetic_alignment
+    O = oracle_mod
+    rng = random.Random(8)
+    pairs = [O.alignment_pair(synthetic_alignment(rng, n, sub=.02, dele=.01, dup=.01)) for n in (40, 256, 4000, 130)]
+    fb = da.ForwardBackward(O.pack_pairs(pairs))
+    counts, ll, per = fb.expectedCounts(da.MutatorParams.fromFlags())
+    st = fb.stats()
+    assert st["pairs_streaming"] >= 1 and st["pairs_onchip"] >= 1
+    oc, oll, oper = O.expected_counts(O.MutatorParams.from_cli(), pairs)
+    assert np.array_equal(per, oper) and np.allclose(counts, oc, rtol=1e-9, atol=1e-300)
+    fb.close()

@@ -324,7 +324,7 @@ def test_row_program_autotune(da, oracle_mod, ref_data, tmp_path, monkeypatch):
     # a machine with a shipped verdict (dnastore_amd/tune/): nothing is timed, nothing is written
     water = da.Machine.compose(da.Machine.fromFile(os.path.join(ref_data, "water64.1.json")), da.Machine.fromFile(os.path.join(ref_data, "l4c4.json")))
     shipped = da.ViterbiDecoder(water, params, options="autotune=1")
-    assert "record tune_" in shipped.tier and "stale" not in shipped.tier
+    assert "record tune_" in shipped.tier          # (whether the record is of this kernel source: tests/test_tune_records.py)
     forced = [da.ViterbiDecoder(water, params, options="plan_order=%d" % v) for v in (1, 2)]
     assert [f for f in os.listdir(tmp_path) if f.startswith("tune_")] == notes
     assert forced[0].tier != forced[1].tier

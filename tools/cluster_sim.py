@@ -51,7 +51,7 @@ class ClusterSim:
         self.states_by_row = [np.nonzero(self.row == k)[0] for k in range(self.K)]
         self.cross = (self.e_remote.sum() + self.n_remote.sum()) / max(1, len(es) + len(ns))
 
-    def run(self, seq, polls, lat, max_cols, fold_same_point=False):
+    def run(self, seq, polls, lat, max_cols, fold_same_point=False, lag=1, load_rows=None):
         """polls: rows at which a sweep polls the inbox (fold what the previous poll loaded, then load).  polls = [0] with
         fold_at_end: the kernel of round 2 (load at row 0, fold behind the last row)."""
         N, K, D = self.N, self.K, self.D
@@ -75,7 +75,7 @@ class ClusterSim:
             Dv = np.full(N, np.inf)                # "fresh"
             DC = np.full(N, NEG); SC = np.full(N, NEG)
             XD = np.full(N, NEG); XS = np.full(N, NEG)          # inboxes (as the owner's loads see them)
-            snapD = np.full(N, NEG); snapS = np.full(N, NEG)    # what the last poll loaded, not folded yet
+            snaps = [(np.full(N, NEG), np.full(N, NEG)) for _ in range(lag)]    # what the last `lag` polls loaded, not folded yet (oldest first)
             flight = []                                          # (arrival time, dst array, d values, s values or None)
             t = 0
             n_sw = 0
@@ -92,15 +92,26 @@ class ClusterSim:
                         else:
                             keep.append(item)
                     flight = keep
-                    if k in polls:
+                    if load_rows is not None:
+                        # one fold per sweep (at row 0, of what the last load returned) and loads at other rows
+                        if k == 0:
+                            snapD, snapS = snaps[-1]
+                            g = snapD > DC
+                            if g.any(): DC = np.where(g, snapD, DC); changed = True
+                            g = snapS > SC
+                            if g.any(): SC = np.where(g, snapS, SC); changed = True
+                        if k in load_rows:
+                            snaps = [(XD.copy(), XS.copy())]
+                    elif k in polls:
                         # fold what the previous poll loaded; load again
                         if fold_same_point:
-                            snapD = XD.copy(); snapS = XS.copy()
+                            snaps = [(XD.copy(), XS.copy())]
+                        snapD, snapS = snaps.pop(0)
                         g = snapD > DC
                         if g.any(): DC = np.where(g, snapD, DC); changed = True
                         g = snapS > SC
                         if g.any(): SC = np.where(g, snapS, SC); changed = True
-                        snapD = XD.copy(); snapS = XS.copy()
+                        snaps.append((XD.copy(), XS.copy()))
                     r = self.states_by_row[k]
                     if len(r):
                         d = DC[r]
@@ -129,7 +140,7 @@ class ClusterSim:
                                 np.maximum.at(DC, self.n_dst[e][loc], dv[loc]); np.maximum.at(SC, self.n_dst[e][loc], sv[loc])
                                 if (~loc).any(): flight.append((t + lat, self.n_dst[e][~loc], dv[~loc], sv[~loc]))
                     t += 1
-                if not changed and not flight and not (snapD > DC).any() and not (snapS > SC).any() and not (XD > DC).any() and not (XS > SC).any():
+                if not changed and not flight and not (XD > DC).any() and not (XS > SC).any():
                     break
                 if n_sw > 400: raise RuntimeError("no convergence")
             out.append(n_sw)
@@ -147,6 +158,8 @@ def main():
     ap.add_argument("--polls", default="1,2,4")
     ap.add_argument("--lat", default="12")
     ap.add_argument("--cols", type=int, default=10)
+    ap.add_argument("--lag", default="1", help="a poll folds what the poll `lag` polls before it loaded")
+    ap.add_argument("--load-rows", default="", help="one fold per sweep at row 0; the loads at these rows (comma separated), one run each")
     args = ap.parse_args()
     wl = bench.workload(da, args.config, args.variant)
     m = wl["machine"]
@@ -155,6 +168,9 @@ def main():
     print("G %d K %d T %d cross edges %.3f" % (sim.G, sim.K, sim.T, sim.cross), flush=True)
     seq = da.tokenize(bench.make_reads(m, 0, 1, payload_bytes=wl["payload_bytes"])[0])
     for lat in (int(v) for v in args.lat.split(",")):
+        for lr in (int(v) for v in args.load_rows.split(",") if v):
+            sw = sim.run(seq, set(), lat, args.cols, load_rows={lr})
+            print("lat %2d  fold at row 0, load at row %d: sweeps/col mean %.1f  %s" % (lat, lr, sw[1:].mean(), sw), flush=True)
         for P in (int(v) for v in args.polls.split(",")):
             if P == 0:
                 polls, same = [0], True      # ideal: an offer is in the destination's LDS cell `lat` units later, seen from row 0 on
@@ -162,8 +178,9 @@ def main():
                 print("lat %2d  poll every row, folded at once: sweeps/col mean %.1f  %s" % (lat, sw[1:].mean(), sw), flush=True)
                 continue
             polls = set((i * sim.K) // P for i in range(P))
-            sw = sim.run(seq, polls, lat, args.cols)
-            print("lat %2d  %d polls per sweep: sweeps/col mean %.1f  %s" % (lat, P, sw[1:].mean(), sw), flush=True)
+            for lag in (int(v) for v in args.lag.split(",")):
+                sw = sim.run(seq, polls, lat, args.cols, lag=lag)
+                print("lat %2d  %d polls per sweep, lag %d: sweeps/col mean %.1f  %s" % (lat, P, lag, sw[1:].mean(), sw), flush=True)
 
 
 if __name__ == "__main__":
