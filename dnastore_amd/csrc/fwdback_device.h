@@ -7,15 +7,17 @@ constexpr int kFbThreads = 64;       // one wave of independent alignment pairs 
 constexpr int kFbMaxLen = 32;
 constexpr int kFbMaxCounts = 21 + kFbMaxLen;
 
-// on-chip kernel (fwdback_onchip.hip): sixteen lanes per pair, two pairs per work-group
-constexpr int kFbLanes = 16;
-constexpr int kFbPairsPerGroup = 2;
-constexpr size_t kFbOnchipLdsLimit = 150 * 1024;   // dynamic LDS a work-group of the on-chip kernel may ask for
-// doubles of LDS one pair needs there (Forward block, checkpoints, two Backward rows per lane + 1, substitution
-// counts, envelope bounds as int16)
-__host__ __device__ constexpr size_t fbOnchipPairDoubles(int maxInLen) {
-  return (size_t)kFbLanes * (kFbLanes * 8 + 2) + (size_t)((maxInLen + 1 + kFbLanes - 1) / kFbLanes) * kFbLanes * 2 +
-         (size_t)(kFbLanes + 1) * kFbLanes * 2 + 16 + ((size_t)(maxInLen + 2) * 2 * sizeof(short) + 7) / 8 + 1;
+// on-chip kernels (fwdback_onchip.hip): W = 16 or 32 lanes per pair (the widest envelope row served), a wave per work-group
+constexpr int kFbWave = 64;
+constexpr size_t kFbOnchipLdsLimit = 64 * 1024;   // dynamic LDS a work-group of the on-chip kernel may ask for (several fit a CU)
+// doubles of LDS one pair needs there: Forward S/D of a block [W][2W + 2], the checkpoint row above it [W][2], the Backward
+// row of the block below [2][W][2], substitution counts and scores [16 + 16], length scores [8], envelope bounds as int16
+__host__ __device__ constexpr size_t fbOnchipPairDoubles(int W, int maxInLen) {
+  return (size_t)W * (2 * W + 2) + (size_t)W * 2 + (size_t)W * 4 + 16 + 16 + 8 + ((size_t)(maxInLen + 2) * 2 * sizeof(short) + 7) / 8 + 1;
+}
+// doubles of global scratch per pair slot: the checkpoints [blocks][W][2] and the duplication lanes of one block [W][W][8]
+__host__ __device__ constexpr size_t fbOnchipSlotDoubles(int W, int maxInLen) {
+  return (size_t)((maxInLen + 1 + W - 1) / W) * W * 2 + (size_t)W * W * 8;
 }
 
 struct FbArgs {

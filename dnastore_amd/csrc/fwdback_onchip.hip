@@ -1,28 +1,36 @@
 // Forward-backward E-step of the mutator pair-HMM, ON CHIP: the banded Forward and Backward matrices of a pair
-// (reference src/fwdback.cpp:43-116) and its posterior counts (fwdback.cpp:154-188, fwdback.h:92-112) never leave
-// the CU.  HBM sees the two sequences, the guide columns and 21+P counts + one log-likelihood per pair.
+// (reference src/fwdback.cpp:43-116) and its posterior counts (fwdback.cpp:154-188, fwdback.h:92-112) never become
+// whole anywhere.  HBM sees the two sequences, the guide columns, 21+P counts + one log-likelihood per pair, and a
+// small per-slot scratch area that stays in L2 / Infinity Cache (checkpoint rows, the duplication lanes of one block).
 //
-// Sixteen lanes work on one pair as a systolic wavefront.  Lane l owns the rows ip = 16b + l of the current block b
-// of sixteen rows; at step a it computes the cell (ip, a - ip) if that lies in the row's envelope [lo(ip), hi(ip)].
-// A cell needs (ip-1, op-1), (ip-1, op) -- the row of lane l-1, one and two steps ago, read back from LDS -- and
-// (ip, op-1), its own previous step, kept in registers.  A row is at most sixteen cells wide, so a lane has left
-// its row before the next block hands it another one.
+// W lanes work on one pair as a systolic wavefront (W = 16 or 32: the widest envelope row the kernel serves).  Lane l owns
+// the rows ip = W*b + l of the current block b of W rows; at step a it computes the cell (ip, a - ip) if that lies in the
+// row's envelope [lo(ip), hi(ip)].  A cell needs (ip-1, op-1) and (ip-1, op) -- what the lane below it computed two steps
+// and one step ago: they come over by a lane shuffle, not through memory -- and (ip, op-1), its own previous step, kept
+// in registers.  A row is at most W cells wide, so a lane has left its row before the next block hands it another one.
 //
 //   pass 1   Forward over all rows; only the S and D lanes of the last row of every block are kept (a "checkpoint",
-//            2 * 16 doubles per block): a row is a function of the S and D lanes of the row above it, because the
-//            duplication lanes T only run along a row (fwdback.cpp:57-60).
-//   pass 2   blocks from the last to the first: the block's Forward rows are recomputed from the checkpoint above it
-//            and kept whole (16 rows x 16 cells x P+2 lanes, 16 KB); then the Backward wavefront runs up the block,
-//            two S/D rows of it alive at a time, and every finished Backward cell adds its seven posterior terms
-//            (fwdback.h:92-112) to the pair's counts.
+//            2 * W doubles per block, in the slot's scratch): a row is a function of the S and D lanes of the row above
+//            it, because the duplication lanes T only run along a row (fwdback.cpp:57-60).
+//   pass 2   blocks from the last to the first: the block's Forward rows are recomputed from the checkpoint above it;
+//            their S and D lanes stay in LDS (W x W cells x 2), their duplication lanes go to the slot's scratch (read
+//            back one cell per step of the Backward wavefront, long before they are used); then the Backward wavefront
+//            runs up the block -- the row below comes over by shuffle, the block below left its first row in LDS -- and
+//            every finished Backward cell adds its seven posterior terms (fwdback.h:92-112) to the pair's counts.
+//
+// LDS per pair: 6.3 KB at W = 16 (round 2 kept the duplication lanes and the checkpoints there too: 26 KB), so a CU holds
+// 24 pairs on 6 full waves instead of 6 pairs on 3 half-filled ones.  A work-group is ONE wave (64 / W pairs) and walks the
+// list of pairs with a stride of the grid; nothing in it needs a work-group barrier.
 //
 // The arithmetic of a cell is the reference's, operation for operation (lse() with the reference's 100 001-entry
-// table, uploaded once per handle and L2 resident): per-pair log-likelihoods are bit-identical to the CPU oracle's.
-// Counts are sums of exp() terms added in another order (per lane, then over the sixteen lanes in a fixed tree),
-// so they agree to ~1e-12 relative and are reproducible run to run.
+// table, uploaded once per handle and L2 resident; the two divisions by the table step are formed with a reciprocal and one
+// fused correction, which gives the correctly rounded quotient -- checked against the division on 4 * 10^8 arguments):
+// per-pair log-likelihoods are bit-identical to the CPU oracle's.  Counts are sums of exp() terms added in another order
+// (per lane, then over the lanes in a fixed tree), so they agree to ~1e-12 relative and are reproducible run to run.
 //
-// LDS per pair ~26 KB -> six pairs per CU: the kernel is bound by the latency chain of a cell (four dependent table
-// look-ups), not by bytes; what is reported is pairs/s, nt/s and log-sum-exp operations per second.
+// What bounds it: the instruction stream of a cell (9 table-interpolated log-sum-exps forward, the same plus 17 fp64 exp
+// backward) -- fp64 vector issue, not bytes: bench.py --config 4 reports the share of the chip's fp64 issue slots the
+// kernel's instructions take.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -31,18 +39,26 @@
 namespace {
 
 constexpr double kNegInf = -__builtin_huge_val();
-constexpr int kL = kFbLanes;            // lanes per pair = rows per block = widest envelope row served
-constexpr int kRS = kL * 8 + 2;         // doubles per Forward row of the block (padded against bank conflicts)
 constexpr int kMaxP = 8;                // duplication lanes this kernel keeps in registers
+
+// x / .0001, correctly rounded, without the division sequence (Markstein: q0 = x * r, e = x - c * q0 exactly, q = q0 + e * r
+// with r the correctly rounded reciprocal); below 1e-280 the residual would underflow: the division itself
+__device__ __forceinline__ double divStep(double x) {
+  constexpr double c = .0001, r = 1.0 / .0001;
+  if (x != 0. && x < 1e-280) return x / c;
+  const double q0 = x * r;
+  const double e = __builtin_fma(-c, q0, x);
+  return __builtin_fma(e, r, q0);
+}
 
 __device__ __forceinline__ double lse_unary(const double* __restrict__ tab, double x) {
   if (x >= 10. || x != x || x == __builtin_huge_val()) return 0;   // logsumexp.h:41-42
   if (x < 0) return -x;
-  const int n = (int)(x / .0001);
+  const int n = (int)divStep(x);                  // (int)(x / .0001)
   const double dx = x - (n * .0001);
   const double f0 = tab[n], f1 = tab[n + 1];
   const double df = f1 - f0;
-  return f0 + df * (dx / .0001);
+  return f0 + df * divStep(dx);                   // f0 + df * (dx / .0001)
 }
 
 __device__ __forceinline__ double lse(const double* __restrict__ tab, double a, double b) {   // logsumexp.h:56-74
@@ -53,52 +69,61 @@ __device__ __forceinline__ double lse(const double* __restrict__ tab, double a, 
   return mx + lse_unary(tab, diff);
 }
 
-}  // namespace
-
-// One work-group = kFbPairsPerGroup pairs (16 lanes each).  pairList[i] = index of the pair in the database.
-// Dynamic LDS: kFbPairsPerGroup * pairDoubles doubles, pairDoubles = fbOnchipPairDoubles(maxInLen).
-extern "C" __global__ void __launch_bounds__(kFbLanes * kFbPairsPerGroup)
-fwdback_onchip_kernel(FbArgs a, const int8_t* __restrict__ inSeqs, const int64_t* __restrict__ inOff,
-                      const int8_t* __restrict__ outSeqs, const int64_t* __restrict__ outOff,
-                      const int32_t* __restrict__ cmIn, const int64_t* __restrict__ cmInOff,
-                      const int32_t* __restrict__ cmOut, const int64_t* __restrict__ cmOutOff,
-                      const double* __restrict__ lseTab, const int64_t* __restrict__ pairList, int64_t nList,
-                      double* __restrict__ pairCounts, double* __restrict__ pairLL, int maxInLen,
-                      unsigned long long* __restrict__ lseOps) {
+// One wave = 64 / W pairs.  pairList[i] = index of the pair in the database; slot scratch: fbOnchipSlotDoubles(W, maxInLen)
+// doubles per pair slot (checkpoints [nCk][W][2], then the duplication lanes of one block [W rows][W cells][8]).
+template <int W>
+__device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_t* __restrict__ inSeqs, const int64_t* __restrict__ inOff,
+                                                    const int8_t* __restrict__ outSeqs, const int64_t* __restrict__ outOff,
+                                                    const int32_t* __restrict__ cmIn, const int64_t* __restrict__ cmInOff,
+                                                    const int32_t* __restrict__ cmOut, const int64_t* __restrict__ cmOutOff,
+                                                    const double* __restrict__ lseTab, const int64_t* __restrict__ pairList, int64_t nList,
+                                                    double* __restrict__ pairCounts, double* __restrict__ pairLL, int maxInLen,
+                                                    unsigned long long* __restrict__ lseOps, double* __restrict__ scratch) {
   extern __shared__ double fbLds[];
-  __shared__ double subS[16], lenS[kMaxP];
-  if (threadIdx.x < 16) subS[threadIdx.x] = a.sub[threadIdx.x];
-  if (threadIdx.x < kMaxP) lenS[threadIdx.x] = a.len[threadIdx.x];
-  const int g = threadIdx.x / kL, l = threadIdx.x % kL;
-  const int64_t item = (int64_t)blockIdx.x * kFbPairsPerGroup + g;
+  constexpr int PPG = 64 / W;                                       // pairs per wave
+  constexpr int kRS = W * 2 + 2;                                    // doubles per Forward row in LDS (padded against bank conflicts)
+  const int g = threadIdx.x / W, l = threadIdx.x % W;
+  const int P = a.P, Dm = a.maxDistance;
+  const int nCk = (maxInLen + 1 + W - 1) / W;                       // blocks (and checkpoints) of the longest pair
+  // LDS of this pair
+  double* const base = fbLds + (size_t)g * fbOnchipPairDoubles(W, maxInLen);
+  double* const FB = base;                                           // [W rows][kRS]: (cell j)*2 + {S, D}
+  double* const CKROW = FB + W * kRS;                                // [W cells][2]: the checkpoint row above the block
+  double* const BRROW = CKROW + W * 2;                               // [2][W cells][2]: Backward S/D of the first row of the block below
+  double* const SUBC = BRROW + 2 * W * 2;                            // [16] substitution counts
+  double* const SUBS_ = SUBC + 16;                                   // [16] the substitution scores
+  double* const LENS_ = SUBS_ + 16;                                  // [kMaxP]
+  short* const LO = reinterpret_cast<short*>(LENS_ + kMaxP);         // [maxInLen + 2]
+  short* const HI = LO + (maxInLen + 2);
+  // scratch of this slot
+  double* const slot = scratch + ((size_t)blockIdx.x * PPG + g) * fbOnchipSlotDoubles(W, maxInLen);
+  double* const CK = slot;                                           // [nCk][W cells][2]
+  double* const TB = slot + (size_t)nCk * W * 2;                     // [W rows][W cells][kMaxP]
+  if (l < 16) SUBS_[l] = a.sub[l];
+  if (l < kMaxP) LENS_[l] = a.len[l];
+  unsigned long long nLse = 0;
+#define LSE(x, y) (++nLse, lse(lseTab, (x), (y)))
+#define SUBS(i, o) SUBS_[in[(i) - 1] * 4 + out[(o) - 1]]                 /* cellSubScore, fwdback.h:65-67 */
+#define DUPS(i, o, k) SUBS_[in[(i) - 1 - (k)] * 4 + out[(o) - 1]]        /* cellTanDupScore, fwdback.h:69-71 */
+#define WAVE_SYNC() __builtin_amdgcn_wave_barrier()                      /* LDS traffic of one wave is in order: a compiler fence */
+#define FROM_LANE(v, src) __shfl((v), (src), W)
+
+  for (int64_t item0 = (int64_t)blockIdx.x * PPG; item0 < nList; item0 += (int64_t)gridDim.x * PPG) {
+  const int64_t item = item0 + g;
   const bool live = item < nList;
   const int64_t pair = live ? pairList[item] : 0;
-  const int P = a.P, Dm = a.maxDistance;
-  const int nCk = (maxInLen + 1 + kL - 1) / kL;                    // blocks (and checkpoints) of the longest pair
-  // LDS of this pair
-  double* const base = fbLds + (size_t)g * fbOnchipPairDoubles(maxInLen);
-  double* const FB = base;                                           // [kL rows][kRS]: (cell j)*8 + lane
-  double* const CK = FB + kL * kRS;                                  // [nCk][kL cells][2]
-  double* const BR = CK + (size_t)nCk * kL * 2;                      // [kL + 1 rows][kL cells][2]
-  double* const SUBC = BR + (kL + 1) * kL * 2;                       // [16] substitution counts
-  short* const LO = reinterpret_cast<short*>(SUBC + 16);             // [maxInLen + 2]
-  short* const HI = LO + (maxInLen + 2);
-
   const int8_t* in = inSeqs + inOff[pair];
   const int8_t* out = outSeqs + outOff[pair];
   const int I = live ? (int)(inOff[pair + 1] - inOff[pair]) : -1;
   const int O = live ? (int)(outOff[pair + 1] - outOff[pair]) : -1;
   const int32_t* ci = cmIn + cmInOff[pair];
   const int32_t* co = cmOut + cmOutOff[pair];
-  unsigned long long nLse = 0;
-#define LSE(x, y) (++nLse, lse(lseTab, (x), (y)))
-#define SUBS(i, o) subS[in[(i) - 1] * 4 + out[(o) - 1]]                 /* cellSubScore, fwdback.h:65-67 */
-#define DUPS(i, o, k) subS[in[(i) - 1 - (k)] * 4 + out[(o) - 1]]        /* cellTanDupScore, fwdback.h:69-71 */
 
   // ---- the envelope of every row (alignpath.h:48-53): op in [lo, hi] <=> |cm(ip) - cm(op)| <= maxDistance; cm is
   // non-decreasing along both sequences, so lo and hi are two binary searches per row
+  WAVE_SYNC();
   if (l < 16) SUBC[l] = 0;
-  for (int ip = l; ip <= I; ip += kL) {
+  for (int ip = l; ip <= I; ip += W) {
     const int lowKey = ci[ip] - Dm, highKey = ci[ip] + Dm;
     int x = 0, y = O + 1;
     while (x < y) { const int mid = (x + y) >> 1; if (co[mid] < lowKey) x = mid + 1; else y = mid; }
@@ -108,12 +133,14 @@ fwdback_onchip_kernel(FbArgs a, const int8_t* __restrict__ inSeqs, const int64_t
     LO[ip] = (short)lo;
     HI[ip] = (short)(x - 1);
   }
-  __syncthreads();
+  WAVE_SYNC();
 
-  const int nBlocks = live ? (I + 1 + kL - 1) / kL : 0;
+  const int nBlocks = live ? (I + 1 + W - 1) / W : 0;
   double ll = kNegInf;
   double T[kMaxP];                                                 // duplication lanes of this lane's previous cell
   double leftS = kNegInf;                                          // (Backward: S of the previous cell of the row)
+#pragma unroll
+  for (int k = 0; k < kMaxP; ++k) T[k] = kNegInf;
 
   // One Forward cell.  upS/upD/diagS: row ip-1 (or -inf outside its envelope); T[]: cell (ip, op-1) when hasIns.
   auto forwardCell = [&](int ip, int op, bool hasIns, double diagS, bool diagIn, double upS, double upD, bool upIn, double& s, double& d) {
@@ -132,117 +159,136 @@ fwdback_onchip_kernel(FbArgs a, const int8_t* __restrict__ inSeqs, const int64_t
       double t = kNegInf;
       if (k < P) {
         if (hasIns && k < mdl - 1) t = T[k + 1] + DUPS(ip, op, k + 1);
-        if (k < mdl) t = LSE(t, s + a.tanDup + lenS[k]);
+        if (k < mdl) t = LSE(t, s + a.tanDup + LENS_[k]);
       }
       tn[k] = t;
     }
 #pragma unroll
     for (int k = 0; k < kMaxP; ++k) T[k] = tn[k];
   };
+  // is (row r, column op) inside the envelope
+  auto inRow = [&](int r, int op) -> bool { return r >= 0 && r <= I && op >= LO[r] && op <= HI[r]; };
 
-  // The S and D lanes of row r-1 for a cell of row r at column op: from `rowBuf` (cells of 8 doubles, the Forward
-  // block) or from a checkpoint (cells of 2 doubles).
-  auto upRow = [&](const double* rowBuf, int stride, int rUp, int op, double& s, double& d) -> bool {
-    const int lo = LO[rUp], hi = HI[rUp];
-    if (op < lo || op > hi) { s = d = kNegInf; return false; }
-    s = rowBuf[(op - lo) * stride];
-    d = rowBuf[(op - lo) * stride + 1];
-    return true;
-  };
-
-  // ---------------- pass 1: Forward, checkpoints only
+  // ---------------- pass 1: Forward, checkpoints only.  What the lane below computed one and two steps ago is this lane's
+  // (ip-1, op) and (ip-1, op-1): the steps are global (a = ip + op), every cell has its one step
   {
     int ip = l;                                                    // this lane's row
     int aNow = live ? LO[0] : 0;                                   // global step = ip + op
     const int aLast = live ? I + HI[I] : -1;
-    // steps are global over all rows: row ip is worked at steps ip + lo(ip) .. ip + hi(ip)
+    double curS = kNegInf, curD = kNegInf, prevS = kNegInf;        // this lane's cell of the step before, S of the one before that
     for (; __any(live && aNow <= aLast) && aNow <= 2 * 65536; ++aNow) {
+      const int below = (l + W - 1) % W;                           // (lane 0 follows lane W-1: its row W*b comes after row W*b - 1)
+      const double uS = FROM_LANE(curS, below), uD = FROM_LANE(curD, below), dS = FROM_LANE(prevS, below);
+      prevS = curS;
       if (live && ip <= I) {
         const int lo = LO[ip], hi = HI[ip];
         const int op = aNow - ip;
         if (op >= lo && op <= hi) {
           const bool hasIns = ip > 0 && op > 0 && op - 1 >= lo;
-          double dS = kNegInf, dD, uS = kNegInf, uD = kNegInf;
-          bool dIn = false, uIn = false;
-          if (ip > 0) {
-            const double* up = FB + ((ip - 1) % kL) * kRS;
-            if (op > 0) dIn = upRow(up, 8, ip - 1, op - 1, dS, dD);
-            uIn = upRow(up, 8, ip - 1, op, uS, uD);
-          }
+          const bool dIn = ip > 0 && op > 0 && inRow(ip - 1, op - 1), uIn = ip > 0 && inRow(ip - 1, op);
           double s, d;
           forwardCell(ip, op, hasIns, dS, dIn, uS, uD, uIn, s, d);
-          double* cell = FB + (ip % kL) * kRS + (op - lo) * 8;
-          cell[0] = s;
-          cell[1] = d;
-          if (ip % kL == kL - 1 || ip == I) {                     // the block's last row is its checkpoint
-            double* ck = CK + ((size_t)(ip / kL) * kL + (op - lo)) * 2;
+          curS = s; curD = d;
+          if (ip % W == W - 1 || ip == I) {                        // the block's last row is its checkpoint
+            double* ck = CK + ((size_t)(ip / W) * W + (op - lo)) * 2;
             ck[0] = s;
             ck[1] = d;
           }
           if (ip == I && op == O) ll = s;                          // loglike = sCell(inLen, outLen), fwdback.cpp:76
-          if (op == hi) ip += kL;                                  // row done: on to this lane's row of the next block
+          if (op == hi) ip += W;                                   // row done: on to this lane's row of the next block
         } else if (op > hi) {
-          ip += kL;                                                // (an empty row)
+          ip += W;                                                 // (an empty row)
         }
       }
     }
   }
   // every lane of the pair needs the log-likelihood; the lane that owned (I, O) has it
-  for (int offs = kL / 2; offs > 0; offs >>= 1) { const double o2 = __shfl_xor(ll, offs, kL); ll = ll < o2 ? o2 : ll; }
+  for (int offs = W / 2; offs > 0; offs >>= 1) { const double o2 = __shfl_xor(ll, offs, W); ll = ll < o2 ? o2 : ll; }
   if (live && l == 0) pairLL[pair] = ll;
+  __threadfence_block();                                           // the checkpoints are read back by other lanes of this wave
 
-  // ---------------- pass 2: per block, Forward again (kept whole), then Backward + counts
+  // ---------------- pass 2: per block, Forward again (S and D kept in LDS, T in the slot's scratch), then Backward + counts
   double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, cl[kMaxP];
 #pragma unroll
   for (int k = 0; k < kMaxP; ++k) cl[k] = 0;
   for (int b = nBlocks - 1; __any(b >= 0); --b) {
     const bool on = live && b >= 0;
-    const int r0 = b * kL, rLast = on ? (r0 + kL - 1 < I ? r0 + kL - 1 : I) : -1;
+    const int r0 = b * W, rLast = on ? (r0 + W - 1 < I ? r0 + W - 1 : I) : -1;
     const int ip = r0 + l;
     const bool mine = on && ip <= rLast;
     const int lo = mine ? LO[ip] : 0, hi = mine ? HI[ip] : -1;
+    // the checkpoint row above the block, from the scratch into LDS (a cell per lane)
+    WAVE_SYNC();
+    if (on && b > 0) {
+      const double* ck = CK + ((size_t)(b - 1) * W + l) * 2;
+      CKROW[l * 2] = ck[0];
+      CKROW[l * 2 + 1] = ck[1];
+    }
+    WAVE_SYNC();
+    const int loUp = (on && ip > 0 && ip - 1 <= I) ? LO[ip - 1] : 0;
     // ---- Forward of the block
     {
       const int aFirst = on ? r0 + LO[r0] : 0, aEnd = on ? rLast + HI[rLast] : -1;
+      double curS = kNegInf, curD = kNegInf, prevS = kNegInf;
       for (int aNow = aFirst; __any(on && aNow <= aEnd); ++aNow) {
+        const int below = l > 0 ? l - 1 : 0;
+        double uS = FROM_LANE(curS, below), uD = FROM_LANE(curD, below), dS = FROM_LANE(prevS, below);
+        prevS = curS;
         const int op = aNow - ip;
         if (mine && op >= lo && op <= hi) {
           const bool hasIns = ip > 0 && op > 0 && op - 1 >= lo;
-          double dS = kNegInf, dD, uS = kNegInf, uD = kNegInf;
-          bool dIn = false, uIn = false;
-          if (ip > 0) {
-            const double* up = l == 0 ? CK + (size_t)(b - 1) * kL * 2 : FB + (l - 1) * kRS;
-            const int stride = l == 0 ? 2 : 8;
-            if (op > 0) dIn = upRow(up, stride, ip - 1, op - 1, dS, dD);
-            uIn = upRow(up, stride, ip - 1, op, uS, uD);
+          const bool dIn = ip > 0 && op > 0 && inRow(ip - 1, op - 1), uIn = ip > 0 && inRow(ip - 1, op);
+          if (l == 0) {                                            // the row above is the checkpoint
+            if (dIn) dS = CKROW[(op - 1 - loUp) * 2];
+            if (uIn) { uS = CKROW[(op - loUp) * 2]; uD = CKROW[(op - loUp) * 2 + 1]; }
           }
           double s, d;
           forwardCell(ip, op, hasIns, dS, dIn, uS, uD, uIn, s, d);
-          double* cell = FB + l * kRS + (op - lo) * 8;
+          curS = s; curD = d;
+          double* cell = FB + l * kRS + (op - lo) * 2;
           cell[0] = s;
           cell[1] = d;
+          double* tb = TB + ((size_t)l * W + (op - lo)) * kMaxP;
 #pragma unroll
-          for (int k = 0; k < kMaxP; ++k) if (k < P) cell[2 + k] = T[k];
+          for (int k = 0; k < kMaxP; ++k) if (k < P) tb[k] = T[k];
         }
       }
     }
+    __threadfence_block();                                         // TB is read back by the same lane, FB by its neighbours
+    WAVE_SYNC();
     // ---- Backward of the block (fwdback.cpp:80-116), anti-diagonals downwards, with the counts
     {
       const int aFirst = on ? rLast + HI[rLast] : -1, aEnd = on ? r0 + LO[r0] : 0;
       const int mdl = ip < P ? ip : P;
       const int nlo = (mine && ip < I) ? LO[ip + 1] : 0, nhi = (mine && ip < I) ? HI[ip + 1] : -1;
-      const double* down = BR + (size_t)(l + 1) * kL * 2;          // row ip+1: the lane above, or the block above (row kL)
-      double* mineB = BR + (size_t)l * kL * 2;
-      const double* upF = l == 0 ? CK + (size_t)(b - 1) * kL * 2 : FB + (l - 1) * kRS;
-      const int upStride = l == 0 ? 2 : 8;
+      const double* const downRow = BRROW + (size_t)((b + 1) & 1) * W * 2;   // the first row of the block below, left by its lane 0
+      double* const mineRow = BRROW + (size_t)(b & 1) * W * 2;               // where this block's lane 0 leaves its row
+      const bool lastLane = l == W - 1;
+      const double* upF = l == 0 ? CKROW : FB + (l - 1) * kRS;
+      double bcurS = kNegInf, bcurD = kNegInf, bprevS = kNegInf;   // Backward cell of the step before, S of the one before that
       for (int aNow = aFirst; __any(on && aNow >= aEnd); --aNow) {
+        const int above = l < W - 1 ? l + 1 : l;
+        double nS = FROM_LANE(bprevS, above), nD = FROM_LANE(bcurD, above);   // (ip+1, op+1).S and (ip+1, op).D
+        bprevS = bcurS;
         const int op = aNow - ip;
         if (mine && op >= lo && op <= hi) {
           const int j = op - lo;
+          // the Forward duplication lanes of the cell to the left, (ip, op-1): on their way while the Backward cell is computed
+          double ft[kMaxP];
+          const bool fIns = op - 1 >= lo;
+          {
+            const double* tb = TB + ((size_t)l * W + (fIns ? j - 1 : 0)) * kMaxP;
+#pragma unroll
+            for (int k = 0; k < kMaxP; ++k) ft[k] = (k < P && fIns) ? tb[k] : kNegInf;
+          }
           double s = (ip == I && op == O) ? 0. : kNegInf, d = kNegInf;
           const bool hasIns = op < O && ip > 0 && op + 1 <= hi;    // (ip, op+1) in range: T[] and leftS are that cell's
-          if (op < O && ip < I && op + 1 >= nlo && op + 1 <= nhi)
-            s = a.noGap + SUBS(ip + 1, op + 1) + down[(op + 1 - nlo) * 2];
+          const bool sIn = op < O && ip < I && op + 1 >= nlo && op + 1 <= nhi, dInB = ip < I && op >= nlo && op <= nhi;
+          if (lastLane) {                                          // the row below belongs to the block below
+            if (sIn) nS = downRow[(op + 1 - nlo) * 2];
+            if (dInB) nD = downRow[(op - nlo) * 2 + 1];
+          }
+          if (sIn) s = a.noGap + SUBS(ip + 1, op + 1) + nS;
           double bt[kMaxP];
 #pragma unroll
           for (int k = 0; k < kMaxP; ++k) {
@@ -250,42 +296,36 @@ fwdback_onchip_kernel(FbArgs a, const int8_t* __restrict__ inSeqs, const int64_t
             if (k < P && hasIns && k < mdl) t = (k == 0) ? DUPS(ip, op + 1, 0) + leftS : DUPS(ip, op + 1, k) + T[k - 1 < 0 ? 0 : k - 1];
             bt[k] = t;
           }
-          if (ip < I && op >= nlo && op <= nhi) {
-            const double dd = down[(op - nlo) * 2 + 1];
-            s = LSE(s, a.delOpen + dd);
-            d = a.delExtend + dd;
+          if (dInB) {
+            s = LSE(s, a.delOpen + nD);
+            d = a.delExtend + nD;
           }
 #pragma unroll
-          for (int k = 0; k < kMaxP; ++k) if (k < mdl) s = LSE(s, bt[k] + a.tanDup + lenS[k]);
+          for (int k = 0; k < kMaxP; ++k) if (k < mdl) s = LSE(s, bt[k] + a.tanDup + LENS_[k]);
           d = LSE(d, s + a.delEnd);
-          mineB[j * 2] = s;
-          mineB[j * 2 + 1] = d;
+          bcurS = s; bcurD = d;
+          if (l == 0) { mineRow[j * 2] = s; mineRow[j * 2 + 1] = d; }
 #pragma unroll
           for (int k = 0; k < kMaxP; ++k) T[k] = bt[k];
           leftS = s;
 
           // ---- posterior counts at (ip, op) (fwdback.h:92-112)
-          const double* fc = FB + l * kRS + j * 8;                 // Forward cell (ip, op); fc - 8: (ip, op-1)
+          const double* fc = FB + l * kRS + j * 2;                 // Forward cell (ip, op): S, D
           if (ip > 0 && op > 0) {
-            double fS, fD;
-            (void)upRow(upF, upStride, ip - 1, op - 1, fS, fD);
+            const double fS = inRow(ip - 1, op - 1) ? upF[(op - 1 - loUp) * 2] : kNegInf;
             const double cS = exp(fS + a.noGap + SUBS(ip, op) + s - ll);                           // pS2S
             c2 += cS;
             double subAdd = cS;
-            const bool fIns = op - 1 >= lo;
 #pragma unroll
             for (int k = 0; k < kMaxP - 1; ++k)
-              if (k < mdl - 1) {
-                const double ft = fIns ? fc[-8 + 2 + k + 1] : kNegInf;
-                atomicAdd(&SUBC[in[ip - 1 - (k + 1)] * 4 + out[op - 1]], exp(ft + DUPS(ip, op, k + 1) + bt[k] - ll));   // pT2T
-              }
-            const double f0 = fIns ? fc[-8 + 2] : kNegInf;
-            subAdd += exp(f0 + DUPS(ip, op, 0) + s - ll);                                          // pT2S
+              if (k < mdl - 1)
+                atomicAdd(&SUBC[in[ip - 1 - (k + 1)] * 4 + out[op - 1]], exp(ft[k + 1] + DUPS(ip, op, k + 1) + bt[k] - ll));   // pT2T
+            subAdd += exp(ft[0] + DUPS(ip, op, 0) + s - ll);                                       // pT2S
             atomicAdd(&SUBC[in[ip - 1] * 4 + out[op - 1]], subAdd);
           }
           if (ip > 0) {
-            double uS, uD;
-            (void)upRow(upF, upStride, ip - 1, op, uS, uD);
+            const bool uIn = inRow(ip - 1, op);
+            const double uS = uIn ? upF[(op - loUp) * 2] : kNegInf, uD = uIn ? upF[(op - loUp) * 2 + 1] : kNegInf;
             c0 += exp(uS + a.delOpen + d - ll);                                                    // pS2D
             c3 += exp(uD + a.delExtend + d - ll);                                                  // pD2D
           }
@@ -294,27 +334,24 @@ fwdback_onchip_kernel(FbArgs a, const int8_t* __restrict__ inSeqs, const int64_t
 #pragma unroll
           for (int k = 0; k < kMaxP; ++k)
             if (k < mdl) {
-              const double cT = exp(fs + a.tanDup + lenS[k] + bt[k] - ll);                        // pS2T
+              const double cT = exp(fs + a.tanDup + LENS_[k] + bt[k] - ll);                        // pS2T
               c1 += cT;
               cl[k] += cT;
             }
         }
       }
-      // the first row of this block is the "row above" of the next (lower) block
-      if (on && mine && l == 0)
-        for (int j = 0; j <= hi - lo; ++j) { BR[(size_t)kL * kL * 2 + j * 2] = mineB[j * 2]; BR[(size_t)kL * kL * 2 + j * 2 + 1] = mineB[j * 2 + 1]; }
     }
   }
-  __syncthreads();
+  WAVE_SYNC();
 
   // ---- the pair's counts: lanes summed in a fixed tree
-  auto sum16 = [&](double v) {
-    for (int offs = kL / 2; offs > 0; offs >>= 1) v += __shfl_xor(v, offs, kL);
+  auto sumW = [&](double v) {
+    for (int offs = W / 2; offs > 0; offs >>= 1) v += __shfl_xor(v, offs, W);
     return v;
   };
-  c0 = sum16(c0); c1 = sum16(c1); c2 = sum16(c2); c3 = sum16(c3); c4 = sum16(c4);
+  c0 = sumW(c0); c1 = sumW(c1); c2 = sumW(c2); c3 = sumW(c3); c4 = sumW(c4);
 #pragma unroll
-  for (int k = 0; k < kMaxP; ++k) cl[k] = sum16(cl[k]);
+  for (int k = 0; k < kMaxP; ++k) cl[k] = sumW(cl[k]);
   if (live) {
     double* pc = pairCounts + (size_t)pair * (21 + P);
     if (l == 0) {
@@ -322,12 +359,30 @@ fwdback_onchip_kernel(FbArgs a, const int8_t* __restrict__ inSeqs, const int64_t
 #pragma unroll
       for (int k = 0; k < kMaxP; ++k) if (k < P) pc[21 + k] = cl[k];
     }
-    pc[5 + l] = SUBC[l];
+    if (l < 16) pc[5 + l] = SUBC[l];
   }
-  // the substitution counts of pS2S belong to cell (in[ip-1], out[op-1]) as well: they were added through subAdd
+  }   // pairs of this slot
   if (lseOps) {
     unsigned long long tot = nLse;
     for (int offs = 32; offs > 0; offs >>= 1) tot += __shfl_xor(tot, offs, 64);
     if ((threadIdx.x & 63) == 0) atomicAdd(lseOps, tot);
   }
+#undef LSE
+#undef SUBS
+#undef DUPS
 }
+
+}  // namespace
+
+#define FB_KERNEL(name, W)                                                                                                        \
+  extern "C" __global__ void __launch_bounds__(64)                                                                                \
+  name(FbArgs a, const int8_t* __restrict__ inSeqs, const int64_t* __restrict__ inOff, const int8_t* __restrict__ outSeqs,        \
+       const int64_t* __restrict__ outOff, const int32_t* __restrict__ cmIn, const int64_t* __restrict__ cmInOff,                 \
+       const int32_t* __restrict__ cmOut, const int64_t* __restrict__ cmOutOff, const double* __restrict__ lseTab,                \
+       const int64_t* __restrict__ pairList, int64_t nList, double* __restrict__ pairCounts, double* __restrict__ pairLL,         \
+       int maxInLen, unsigned long long* __restrict__ lseOps, double* __restrict__ scratch) {                                     \
+    fwdback_onchip_body<W>(a, inSeqs, inOff, outSeqs, outOff, cmIn, cmInOff, cmOut, cmOutOff, lseTab, pairList, nList, pairCounts, \
+                           pairLL, maxInLen, lseOps, scratch);                                                                    \
+  }
+FB_KERNEL(fwdback_onchip16_kernel, 16)
+FB_KERNEL(fwdback_onchip32_kernel, 32)

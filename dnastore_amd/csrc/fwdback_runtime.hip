@@ -19,9 +19,10 @@
 extern "C" __global__ void fwdback_estep_kernel(FbArgs, const int8_t*, const int64_t*, const int8_t*, const int64_t*,
                                                 const int32_t*, const int64_t*, const int32_t*, const int64_t*,
                                                 const double*, double*, double*, double*, double*, int64_t, int, int64_t, const int64_t*);
-extern "C" __global__ void fwdback_onchip_kernel(FbArgs, const int8_t*, const int64_t*, const int8_t*, const int64_t*,
-                                                 const int32_t*, const int64_t*, const int32_t*, const int64_t*,
-                                                 const double*, const int64_t*, int64_t, double*, double*, int, unsigned long long*);
+#define FB_ONCHIP_ARGS FbArgs, const int8_t*, const int64_t*, const int8_t*, const int64_t*, const int32_t*, const int64_t*, const int32_t*, \
+                       const int64_t*, const double*, const int64_t*, int64_t, double*, double*, int, unsigned long long*, double*
+extern "C" __global__ void fwdback_onchip16_kernel(FB_ONCHIP_ARGS);
+extern "C" __global__ void fwdback_onchip32_kernel(FB_ONCHIP_ARGS);
 extern "C" __global__ void fwdback_reduce_kernel(const double*, const double*, int64_t, int, double*);
 
 #define HIP_TRY(expr)                                                                          \
@@ -73,12 +74,16 @@ struct dnas_fb {
   double *dCounts = nullptr, *dLL = nullptr, *dPartial = nullptr;
   unsigned long long* dLseOps = nullptr;
   // per guide mode (0: the envelope is maxDistance = P wide, 1: strict) and P: which kernel takes which pair
-  struct Route { int P = -1; int maxInOnchip = 0; std::vector<int64_t> onchip, streaming; std::vector<int64_t> cells; std::vector<int> width;
-                 int64_t* dOnchip = nullptr; int64_t* dStreaming = nullptr; };
+  // (onchip[0]: envelope rows of at most 16 cells, 16 lanes per pair; onchip[1]: up to 32 cells, 32 lanes per pair)
+  struct Route { int P = -1; int maxInOnchip[2] = {0, 0}; std::vector<int64_t> onchip[2], streaming; std::vector<int64_t> cells; std::vector<int> width;
+                 int64_t* dOnchip[2] = {nullptr, nullptr}; int64_t* dStreaming = nullptr; };
   Route route[2];
   // streaming kernel arenas
   double *dFwd = nullptr, *dRows = nullptr;
   size_t fwdBytes = 0, rowsBytes = 0;
+  double* dScratch = nullptr;        // on-chip kernels: checkpoints and duplication lanes of the pair slots
+  size_t scratchBytes = 0;
+  int cus = 256;
   dnas_fb_stats stats{};
 };
 
@@ -91,7 +96,7 @@ void fbFreeDatabase(dnas_fb* h) {
   h->dIn = h->dOut = nullptr; h->dInOff = h->dOutOff = h->dCiOff = h->dCoOff = nullptr; h->dCi = h->dCo = nullptr;
   h->dCounts = h->dLL = h->dPartial = nullptr;
   for (auto& r : h->route) {
-    if (r.dOnchip) (void)hipFree(r.dOnchip);
+    for (int64_t* q : r.dOnchip) if (q) (void)hipFree(q);
     if (r.dStreaming) (void)hipFree(r.dStreaming);
     r = dnas_fb::Route{};
   }
@@ -119,6 +124,7 @@ extern "C" int dnas_fb_create(int device_id, dnas_fb** out) {
   HIP_TRY(hipMalloc((void**)&h->dTab, tab.size() * sizeof(double)));
   HIP_TRY(hipMemcpy(h->dTab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc((void**)&h->dLseOps, sizeof(unsigned long long)));
+  (void)hipDeviceGetAttribute(&h->cus, hipDeviceAttributeMultiprocessorCount, device_id);
 #undef cleanup
   *out = h;
   return DNAS_OK;
@@ -129,7 +135,7 @@ extern "C" void dnas_fb_destroy(dnas_fb* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   fbFreeDatabase(h);
-  for (void* q : {(void*)h->dTab, (void*)h->dFwd, (void*)h->dRows, (void*)h->dLseOps})
+  for (void* q : {(void*)h->dTab, (void*)h->dFwd, (void*)h->dRows, (void*)h->dLseOps, (void*)h->dScratch})
     if (q) (void)hipFree(q);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -216,22 +222,23 @@ extern "C" int dnas_fb_estep(dnas_fb* h, const dnas_mutator_params* p, int stric
       a.sub[i * 4 + j] = (i == j ? std::log(pMatch) : (isTransition(i, j) ? std::log(p->p_transition) : std::log(p->p_transversion / 2))) - nullScore;
   for (int k = 0; k < P; ++k) a.len[k] = std::log(p->p_len[k]);
 
-  // ---- which kernel takes which pair: the on-chip kernel serves envelope rows of up to 16 cells and up to 8
-  // duplication lengths; the census depends on the envelope half-width (P, or 0 with strict guides) and is kept
+  // ---- which kernel takes which pair: the on-chip kernels serve envelope rows of up to 16 or 32 cells (16 or 32 lanes per
+  // pair) and up to 8 duplication lengths; the census depends on the envelope half-width (P, or 0 with strict guides) and is kept
   dnas_fb::Route& rt = h->route[strict ? 1 : 0];
   if (rt.P != P) {
-    if (rt.dOnchip) { (void)hipFree(rt.dOnchip); rt.dOnchip = nullptr; }
+    for (int64_t*& q : rt.dOnchip) { if (q) (void)hipFree(q); q = nullptr; }
     if (rt.dStreaming) { (void)hipFree(rt.dStreaming); rt.dStreaming = nullptr; }
-    rt.onchip.clear(); rt.streaming.clear();
+    rt.onchip[0].clear(); rt.onchip[1].clear(); rt.streaming.clear();
     rt.cells.assign((size_t)n_pairs, 1);
     rt.width.assign((size_t)n_pairs, 1);
     const int Dm = a.maxDistance;
     const bool forceStreaming = getenv("DNAS_FB_STREAMING") != nullptr;
-    // the on-chip kernel keeps a pair's checkpoints and envelope bounds in LDS: a pair whose input is too long for that goes
-    // to the streaming kernel like the pairs with wide envelope rows (never fail the call for it)
-    int longestOnchip = 0;
-    while (kFbPairsPerGroup * fbOnchipPairDoubles(longestOnchip + 64) * sizeof(double) <= kFbOnchipLdsLimit) longestOnchip += 64;
-    rt.maxInOnchip = 0;
+    // the on-chip kernels keep a pair's envelope bounds in LDS: a pair whose input is too long for that goes to the streaming
+    // kernel like the pairs with wider envelope rows (never fail the call for it)
+    int longest[2] = {0, 0};
+    for (int w = 0; w < 2; ++w)
+      while ((size_t)(kFbWave / (16 << w)) * fbOnchipPairDoubles(16 << w, longest[w] + 64) * sizeof(double) <= kFbOnchipLdsLimit) longest[w] += 64;
+    rt.maxInOnchip[0] = rt.maxInOnchip[1] = 0;
     for (int64_t i = 0; i < n_pairs; ++i) {
       const int64_t inLen = h->inOff[i + 1] - h->inOff[i], outLen = h->outOff[i + 1] - h->outOff[i];
       const int32_t* ci = h->ci.data() + h->ciOff[i];
@@ -247,16 +254,21 @@ extern "C" int dnas_fb_estep(dnas_fb* h, const dnas_mutator_params* p, int stric
       }
       rt.cells[(size_t)i] = std::max<int64_t>(tot, 1);
       rt.width[(size_t)i] = w;
-      const bool chip = w <= kFbLanes && P <= 8 && inLen <= longestOnchip && !forceStreaming;
-      (chip ? rt.onchip : rt.streaming).push_back(i);
-      if (chip) rt.maxInOnchip = std::max<int>(rt.maxInOnchip, (int)inLen);
+      const int kind = w <= 16 ? 0 : (w <= 32 ? 1 : 2);
+      const bool chip = kind < 2 && P <= 8 && inLen <= longest[kind] && outLen < 32000 && !forceStreaming;
+      (chip ? rt.onchip[kind] : rt.streaming).push_back(i);
+      if (chip) rt.maxInOnchip[kind] = std::max<int>(rt.maxInOnchip[kind], (int)inLen);
     }
+    // the pairs of a wave walk in step: neighbours in the list should be of a length (longest first)
+    for (auto& list : rt.onchip)
+      std::stable_sort(list.begin(), list.end(), [&](int64_t x, int64_t y) { return h->inOff[x + 1] - h->inOff[x] > h->inOff[y + 1] - h->inOff[y]; });
     auto put = [&](const std::vector<int64_t>& v, int64_t** d) -> hipError_t {
       hipError_t e = hipMalloc((void**)d, std::max<size_t>(v.size(), 1) * sizeof(int64_t));
       if (e == hipSuccess && !v.empty()) e = hipMemcpy(*d, v.data(), v.size() * sizeof(int64_t), hipMemcpyHostToDevice);
       return e;
     };
-    HIP_TRY(put(rt.onchip, &rt.dOnchip));
+    HIP_TRY(put(rt.onchip[0], &rt.dOnchip[0]));
+    HIP_TRY(put(rt.onchip[1], &rt.dOnchip[1]));
     HIP_TRY(put(rt.streaming, &rt.dStreaming));
     rt.P = P;
   }
@@ -270,13 +282,24 @@ extern "C" int dnas_fb_estep(dnas_fb* h, const dnas_mutator_params* p, int stric
   HIP_TRY(hipMemsetAsync(h->dLseOps, 0, sizeof(unsigned long long), h->stream));
   HIP_TRY(hipEventRecord(h->ev0, h->stream));
 
-  // ---- on-chip kernel: two pairs per work-group, everything in LDS
-  if (!rt.onchip.empty()) {
-    const size_t lds = kFbPairsPerGroup * fbOnchipPairDoubles(rt.maxInOnchip) * sizeof(double);   // <= kFbOnchipLdsLimit by the routing
-    const int64_t nL = (int64_t)rt.onchip.size();
-    hipLaunchKernelGGL(fwdback_onchip_kernel, dim3((unsigned)((nL + kFbPairsPerGroup - 1) / kFbPairsPerGroup)), dim3(kFbLanes * kFbPairsPerGroup),
-                       lds, h->stream, a, h->dIn, h->dInOff, h->dOut, h->dOutOff, h->dCi, h->dCiOff, h->dCo, h->dCoOff, h->dTab, rt.dOnchip, nL,
-                       h->dCounts, h->dLL, rt.maxInOnchip, h->dLseOps);
+  // ---- on-chip kernels: a wave per work-group (4 pairs of 16 lanes, or 2 of 32), persistent over the list
+  for (int w = 0; w < 2; ++w) {
+    if (rt.onchip[w].empty()) continue;
+    const int W = 16 << w, ppg = kFbWave / W;
+    const size_t lds = (size_t)ppg * fbOnchipPairDoubles(W, rt.maxInOnchip[w]) * sizeof(double);   // <= kFbOnchipLdsLimit by the routing
+    const int64_t nL = (int64_t)rt.onchip[w].size();
+    const int perCu = std::max(1, std::min(8, (int)((size_t)(150 * 1024) / lds)));
+    const unsigned grid = (unsigned)std::min<int64_t>((nL + ppg - 1) / ppg, (int64_t)h->cus * perCu);
+    const size_t need = (size_t)grid * ppg * fbOnchipSlotDoubles(W, rt.maxInOnchip[w]) * sizeof(double);
+    if (need > h->scratchBytes) {
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      if (h->dScratch) { (void)hipFree(h->dScratch); h->dScratch = nullptr; h->scratchBytes = 0; }
+      HIP_TRY(hipMalloc((void**)&h->dScratch, need));
+      h->scratchBytes = need;
+    }
+    hipLaunchKernelGGL(w == 0 ? fwdback_onchip16_kernel : fwdback_onchip32_kernel, dim3(grid), dim3(kFbWave), lds, h->stream, a, h->dIn, h->dInOff,
+                       h->dOut, h->dOutOff, h->dCi, h->dCiOff, h->dCo, h->dCoOff, h->dTab, rt.dOnchip[w], nL, h->dCounts, h->dLL, rt.maxInOnchip[w],
+                       h->dLseOps, h->dScratch);
     HIP_TRY(hipGetLastError());
   }
   // ---- streaming kernel for the rest: the interleaved Forward arena holds cellCap cells for each of B pairs
@@ -338,7 +361,7 @@ extern "C" int dnas_fb_estep(dnas_fb* h, const dnas_mutator_params* p, int stric
   float ms = 0;
   HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
   h->stats.kernel_ms = ms;
-  h->stats.pairs_onchip = (int64_t)rt.onchip.size();
+  h->stats.pairs_onchip = (int64_t)(rt.onchip[0].size() + rt.onchip[1].size());
   h->stats.pairs_streaming = (int64_t)rt.streaming.size();
   h->stats.lse_ops = (int64_t)ops;
   int64_t ntOut = 0;

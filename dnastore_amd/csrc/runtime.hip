@@ -66,6 +66,7 @@ struct TierALaunch {
   int nClusters;
   int nReads;
   unsigned long long timeoutTicks;
+  unsigned long long arriveTicks;
   const int* colRange;          // bounded-memory decode: [nReads][2] first and last column of this launch (null: whole reads)
 };
 
@@ -87,8 +88,9 @@ struct dnas_model {
   unsigned* dSync = nullptr;    // tier C: sync blocks (64 u32 per cluster)
   unsigned* dFoldTab = nullptr; // tier C: inbox slot -> LDS cells, per member
   size_t xStride = 0;           // doubles per cluster in dXbuf
-  unsigned long long timeoutTicks = 0;
-  std::vector<unsigned> syncCheck;   // host copies of the sync blocks of every launch of the last call (watchdog, placement census)
+  unsigned long long timeoutTicks = 0, arriveTicks = 0;
+  unsigned* syncCheck = nullptr;     // pinned host copies of the sync blocks of every launch of the last call (watchdog, placement census)
+  size_t syncCheckWords = 0, syncCheckCap = 0;
   size_t syncLaunches = 0;
   unsigned clustersSeen = 0, clustersSplit = 0;   // last call: clusters that ran, clusters whose members sat on more than one XCD
   std::string tierNote;
@@ -183,9 +185,10 @@ int collect_stats(dnas_model* m) {
   m->statsPending = false;
   if (m->tier == 2) {
     unsigned xccMixed = 0, clusters = 0;
-    for (size_t c = 0; c * 64 < m->syncCheck.size(); ++c) {
-      const unsigned* w = m->syncCheck.data() + c * 64;
-      if (w[1]) return dnas::fail(DNAS_E_DEVICE, "tier C: a cluster did not agree on a lattice column within the watchdog time (launch aborted)");
+    for (size_t c = 0; c * 64 < m->syncCheckWords; ++c) {
+      const unsigned* w = m->syncCheck + c * 64;
+      if (w[1]) return dnas::fail(DNAS_E_DEVICE, "tier C: a cluster did not agree on a lattice column within the watchdog time, or its work-groups were "
+                                                 "not all started within the arrival time (launch aborted; options cluster_timeout_s, cluster_arrive_s)");
       if (w[40]) { ++clusters; if (w[40] & (w[40] - 1)) ++xccMixed; }
     }
     m->clustersSeen = clusters; m->clustersSplit = xccMixed;
@@ -482,10 +485,17 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
           } else {
             // a cluster lives on one XCD (32 CUs): floor(32 / G) clusters per XCD.  Every cluster owns an exchange
             // buffer (3 arrays of G * GROWS * T cells + the end-of-read reduction cells) and a sync block.
-            int cus = 256;
+            // The members of a cluster wait for each other, so all of them must be resident together: the grid is sized
+            // from what the device says it can hold of THIS kernel (one work-group per CU is what the plan aims at; were it
+            // none, the launch could never finish).  Work-groups are dispatched in index order and a cluster's members are
+            // neighbours in it (groups of 8 clusters), so whatever else holds CUs -- another process, this model's traceback --
+            // delays at most the last clusters of a launch until CUs come free; the kernel gives late members time (below).
+            int cus = 256, perCu = 0;
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id);
+            if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, m->fillA, p.T, p.ldsBytes) != hipSuccess || perCu < 1)
+              throw std::runtime_error("the cluster kernel cannot be resident on this device (occupancy " + std::to_string(perCu) + ")");
             const int xcds = std::max(1, cus / 32);
-            m->maxClusters = std::max(1, xcds * ((cus / xcds) / p.G));
+            m->maxClusters = std::max(1, xcds * ((cus / xcds) / p.G));      // one work-group per CU, whole clusters per XCD
             if (const char* s = opt("max_clusters")) m->maxClusters = std::max(1, atoi(s));
             m->xStride = 3 * (size_t)p.exchangeCells() + 8;
             if (hipMalloc((void**)&m->dXbuf, m->xStride * (size_t)m->maxClusters * sizeof(double)) != hipSuccess ||
@@ -496,6 +506,9 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
             double seconds = 2.0;   // watchdog per lattice column (a column takes tens of microseconds)
             if (const char* s = opt("cluster_timeout_s")) seconds = std::max(0.001, atof(s));
             m->timeoutTicks = (unsigned long long)(seconds * 1e8);   // s_memrealtime counts at 100 MHz
+            double arrive = 60.0;   // ... and for the work-groups of a cluster to have all been started (CUs held by others)
+            if (const char* s = opt("cluster_arrive_s")) arrive = std::max(0.001, atof(s));
+            m->arriveTicks = (unsigned long long)(arrive * 1e8);
             m->tier = 2;
             m->tierNote = "tier C: " + std::to_string(p.G) + " work-groups per read, " + std::to_string(m->maxClusters) +
                           " clusters, exchange edges " + std::to_string(p.crossEdges) + ", " + p.key + "; " + recordNote;
@@ -561,6 +574,7 @@ extern "C" void dnas_model_destroy(dnas_model* m) {
   if (m->dXbuf) (void)hipFree(m->dXbuf);
   if (m->dSync) (void)hipFree(m->dSync);
   if (m->dFoldTab) (void)hipFree(m->dFoldTab);
+  if (m->syncCheck) (void)hipHostFree(m->syncCheck);
   if (m->dEvents) (void)hipFree(m->dEvents);
   if (m->dEvOff) (void)hipFree(m->dEvOff);
   if (m->dEvLen) (void)hipFree(m->dEvLen);
@@ -737,7 +751,7 @@ struct FillLauncher {
       return DNAS_OK;
     }
     TierALaunch la{m->argsA, m->dEntTab, m->dMetaTab, d_bases, m->dReadOff, batchRead, slots,
-                   m->arena, d_out_loglike, m->dRounds, nullptr, nullptr, nullptr, 0, nB, 0ull, colRange};
+                   m->arena, d_out_loglike, m->dRounds, nullptr, nullptr, nullptr, 0, nB, 0ull, 0ull, colRange};
     unsigned grid = (unsigned)nB;
     int nClusters = 0;
     if (m->tier == 2) {
@@ -746,7 +760,7 @@ struct FillLauncher {
       // 8 blocks apart, cluster = (b / 8 / G) * 8 + b % 8.
       const int G = m->plan.G;
       nClusters = std::min(nB, m->maxClusters);
-      la.xbuf = m->dXbuf; la.syncWords = m->dSync; la.foldTab = m->dFoldTab; la.nClusters = nClusters; la.timeoutTicks = m->timeoutTicks;
+      la.xbuf = m->dXbuf; la.syncWords = m->dSync; la.foldTab = m->dFoldTab; la.nClusters = nClusters; la.timeoutTicks = m->timeoutTicks; la.arriveTicks = m->arriveTicks;
       grid = (unsigned)(8 * G * ((nClusters + 7) / 8));
       const size_t nX = m->xStride * (size_t)nClusters;
       hipLaunchKernelGGL(fill_neginf_kernel, dim3((unsigned)((nX + 255) / 256)), dim3(256), 0, m->stream, m->dXbuf, nX);
@@ -759,7 +773,7 @@ struct FillLauncher {
                                   m->stream, nullptr, config));
     if (m->tier == 2) {
       // the watchdog words of this launch: [1] of every sync block (checked in dnas_model_sync)
-      HIP_TRY(hipMemcpyAsync(m->syncCheck.data() + syncAt * (size_t)m->maxClusters * 64, m->dSync,
+      HIP_TRY(hipMemcpyAsync(m->syncCheck + syncAt * (size_t)m->maxClusters * 64, m->dSync,
                              (size_t)nClusters * 64 * sizeof(unsigned), hipMemcpyDeviceToHost, m->stream));
       ++syncAt;
     }
@@ -959,7 +973,14 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
     m->sync.push_back(e);
   }
   if (m->tier == 2) {
-    m->syncCheck.assign((nBatches + cp.groupLaunches) * (size_t)m->maxClusters * 64, 0u);
+    m->syncCheckWords = (nBatches + cp.groupLaunches) * (size_t)m->maxClusters * 64;
+    if (m->syncCheckWords > m->syncCheckCap) {
+      if (m->syncCheck) (void)hipHostFree(m->syncCheck);
+      m->syncCheck = nullptr; m->syncCheckCap = 0;
+      HIP_TRY(hipHostMalloc((void**)&m->syncCheck, m->syncCheckWords * sizeof(unsigned), hipHostMallocDefault));   // pinned: the copies after each fill stay asynchronous
+      m->syncCheckCap = m->syncCheckWords;
+    }
+    memset(m->syncCheck, 0, m->syncCheckWords * sizeof(unsigned));
     m->syncLaunches = nBatches + cp.groupLaunches;
   }
 
@@ -1181,7 +1202,7 @@ extern "C" int dnas_tierc_precompile(const dnas_flat_model* fm, int32_t members,
     dnas::PlanChoice choice;      // as a model of this machine will be planned: the environment, else its tuning record
     if (!getenv("DNAS_PLAN_ORDER") && !getenv("DNAS_PLAN_SLACK") && !(getenv("DNAS_RECORDS") && atoi(getenv("DNAS_RECORDS")) == 0))
       (void)parse_plan_record(dnas::cacheNoteRead(tune_record_name(fm, members >= 2 ? members : 0, 0)), &choice);
-    const dnas::TierAPlan p = dnas::chooseClusterPlan(*fm, members, 0, choice);
+    const dnas::TierAPlan p = dnas::chooseClusterPlan(*fm, members, getenv("DNAS_THREADS") ? atoi(getenv("DNAS_THREADS")) : 0, choice);
     if (!p.ok) return dnas::fail(DNAS_E_UNSUPPORTED, p.whyNot);
     (void)dnas::jitCompile(p.defines, p.key);
     const std::string msg = "tier C: G=" + std::to_string(p.G) + " K=" + std::to_string(p.K) + " inbox rows " + std::to_string(p.nGRows) +

@@ -81,11 +81,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 #define DNAS_GSROWS DNAS_GROWS
 #endif
 #ifndef DNAS_POLLS
-#define DNAS_POLLS 1   // tier C: how often a sweep looks into the inbox (the polls are spread evenly over the rows)
-#endif
-#ifndef DNAS_POLL_SPLIT
-#define DNAS_POLL_SPLIT 0
-#endif
+#define DNAS_POLLS 0   // tier C: 0 = the inbox is loaded behind the last row of a sweep and folded in front of the first row of the
+#endif                 // next one; n > 0 = n polls spread over the rows of a sweep, each folding what the one before it loaded
 #ifndef DNAS_POLL_LAG
 #define DNAS_POLL_LAG 1   // ... and a poll folds what the poll DNAS_POLL_LAG polls before it loaded (DNAS_POLLS is a multiple of it)
 #endif
@@ -167,8 +164,11 @@ __device__ __forceinline__ u32x4 makeDesc(const void* base) {
   d.x = (unsigned)b; d.y = (unsigned)(b >> 32); d.z = 0xffffffffu; d.w = 0x00020000u;
   return d;
 }
+// The compiler does not look into the statement: the wait states a VMEM instruction needs behind a VALU write of a scalar
+// register it reads (v_readlane restores a spilled descriptor right in front of it: five) are spent by the s_nop, and the
+// uniform part of the offset travels in the vector offset, so that the descriptor is the only scalar operand.
 __device__ __forceinline__ void xMax(u32x4 desc, unsigned laneOff, unsigned uniOff, double v) {
-  asm volatile("buffer_atomic_max_f64 %0, %1, %2, %3 offen" : : "v"(v), "v"(laneOff), "s"(desc), "s"(uniOff) : "memory");
+  asm volatile("s_nop 4\n\tbuffer_atomic_max_f64 %0, %1, %2, 0 offen" : : "v"(v), "v"(laneOff + uniOff), "s"(desc) : "memory");
 }
 __device__ __forceinline__ double xLoad(rsrc_t r, unsigned laneOff, unsigned uniOff) {
   return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)laneOff, (int)uniOff, kAuxSc1));
@@ -219,7 +219,8 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
                    double* __restrict__ arena, double* __restrict__ outLoglike,
                    unsigned long long* __restrict__ roundsTotal,
                    double* __restrict__ xbuf, unsigned* __restrict__ syncWords, const unsigned* __restrict__ foldTab,   // [G][GROWS][T]
-                   int nClusters, int nReads, unsigned long long timeoutTicks,
+                   int nClusters, int nReads, unsigned long long timeoutTicks,   // watchdog per lattice column (100 MHz ticks)
+                   unsigned long long arriveTicks,    // ... and for the members of a cluster to have all started
                    const int* __restrict__ colRange) {   // [nReads][2] first and last column to fill, or null: 0 .. L
   extern __shared__ double lds[];
   extern __shared__ unsigned ldsU[];
@@ -357,6 +358,10 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
   unsigned geBase = 0, colSeq = 0, xDirty = 0;
   bool aborted = false;
   unsigned long long tStart = 0ull;   // watchdog: a column that takes longer than timeoutTicks (100 MHz) aborts the launch
+  // The first barrier of a launch is where a cluster's members find each other.  A member may not have been STARTED yet (the
+  // work-groups of another kernel, of another process, of this model's own traceback hold its CU): that is no fault of the
+  // protocol, and it is waited for far longer (arriveTicks) than a lattice column may take once everybody is there.
+  bool arrived = false;
   // all offers of this work-group into the exchange buffer have completed -> bump -> wait for every member
   auto clusterBarrier = [&]() {
     if constexpr (G_ > 1) {
@@ -369,14 +374,15 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
           const unsigned v = tid < 2 ? wLoad(&SY[tid]) : 0u;
           const unsigned ge = __shfl(v, 0, 64), ab = __shfl(v, 1, 64);
           if ((int)(ge - geBase) >= 0) break;
-          if (ab || ((spin & 255u) == 255u && __builtin_amdgcn_s_memrealtime() - tStart > timeoutTicks)) {
+          if (ab || ((spin & 255u) == 255u && __builtin_amdgcn_s_memrealtime() - tStart > (arrived ? timeoutTicks : arriveTicks))) {
             if (tid == 0) { __hip_atomic_store(&SY[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *abortL = 1u; }
             break;
           }
-          __builtin_amdgcn_s_sleep(2);
+          if (arrived) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(20);
         }
       }
       __syncthreads();
+      arrived = true;
       aborted = *abortL != 0u;
     }
   };
@@ -518,21 +524,23 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
       unsigned geSeen = geBase;
       bool pendingBump = false;
       xDirty = 0;
-      // The inbox is looked into DNAS_POLLS times per sweep.  A poll folds what the poll DNAS_POLL_LAG polls BEFORE it loaded
-      // (those loads have arrived by now: a load of a cell that another member's atomic has just touched comes from the
-      // memory side, about two microseconds) into the LDS accumulators of the states behind the slots, and loads the slots
-      // again: what another member offers reaches its state's row within half a sweep instead of a sweep and a half
-      // (tools/cluster_sim.py: 13-14 sweeps per column instead of 18.6 on the 46 670-state machine).
-      constexpr int kPollStride = (K + DNAS_POLLS - 1) / DNAS_POLLS, kLag = DNAS_POLL_LAG;
-      static_assert(DNAS_POLLS % DNAS_POLL_LAG == 0, "the polls of a sweep take the register sets in turn");
+      // How a sweep looks into the inbox.  Every load of a cell goes to the memory side (the atomics of the other members are
+      // performed there), and a wait for load data also waits for every older memory operation of the wave -- its own exchange
+      // atomics included --, so each look costs a stall of about a microsecond whatever its place.  The default (DNAS_POLLS 0)
+      // takes one per sweep where it hurts least and helps most: the cells are loaded behind the last row of a sweep and
+      // folded in front of the first row of the next, so that what lands during a sweep is in its state's accumulator before
+      // that state's row is evaluated again (13.7 sweeps per column on the 46 670-state machine against 17.3 with the load at
+      // the start and the fold at the end of the same sweep; tools/cluster_sim.py predicts both).  DNAS_POLLS = n > 0: n
+      // polls spread over the rows, each folding what the poll before it loaded (fewer sweeps still -- 12.1 at n = 4 -- but a
+      // stall per poll: slower in all).  Whatever the mode, a wave that thinks itself idle first folds the loads it ISSUED IN
+      // THAT SWEEP (the confirmation below): the cluster's termination rests on every wave having looked, after the last value of
+      // GE was imported, at cells loaded after that import.
+      constexpr bool kSplit = DNAS_POLLS == 0;
+      constexpr int kPollStride = kSplit ? K + 1 : (K + DNAS_POLLS - 1) / (DNAS_POLLS > 0 ? DNAS_POLLS : 1);
       constexpr int RS_ = DNAS_GSROWS > 0 ? DNAS_GSROWS : 1;
-      double xd[kLag][R_], xs[kLag][RS_], lastD[R_], lastS[RS_];   // last*: what has been folded (the cells were cleared in phase C)
-      static_for<0, R_>([&](auto rc) { lastD[rc.value] = kNegInf; });
-      static_for<0, RS_>([&](auto rc) { lastS[rc.value] = kNegInf; });
-      static_for<0, kLag>([&](auto lc) {
-        static_for<0, R_>([&](auto rc) { xd[lc.value][rc.value] = kNegInf; });
-        static_for<0, RS_>([&](auto rc) { xs[lc.value][rc.value] = kNegInf; });
-      });
+      double xd[1][R_], xs[1][RS_], lastD[R_], lastS[RS_];   // last*: what has been folded (the cells were cleared in phase C)
+      static_for<0, R_>([&](auto rc) { lastD[rc.value] = kNegInf; xd[0][rc.value] = kNegInf; });
+      static_for<0, RS_>([&](auto rc) { lastS[rc.value] = kNegInf; xs[0][rc.value] = kNegInf; });
       for (;;) {
         asm volatile("" ::: "memory");   // other waves write LDS between sweeps: reload everything
         const unsigned e0 = __hip_atomic_load(epochL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -570,8 +578,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
             });
           }
         };
-        // DNAS_POLL_SPLIT: one poll per sweep, loaded behind the last row and folded in front of the first row of the next sweep
-        auto pollInbox = [&](auto setc) { foldInbox(setc); if constexpr (!DNAS_POLL_SPLIT) loadInbox(setc); };
+        if constexpr (G_ > 1 && kSplit) foldInbox(IntC<0>{});      // what was loaded behind the last row of the sweep before
         // One row of the sweep; dIn / scIn: its accumulators as read.
         auto rowEval = [&](auto kc, double dIn, double scIn) {
           constexpr int k = kc.value, o = rowOffset(k);
@@ -625,7 +632,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
         };
         static_for<0, K>([&](auto kc) {
           constexpr int k = kc.value;
-          if constexpr (G_ > 1 && k % kPollStride == 0) pollInbox(IntC<(k / kPollStride) % kLag>{});
+          if constexpr (G_ > 1 && !kSplit && k % kPollStride == 0) { foldInbox(IntC<0>{}); loadInbox(IntC<0>{}); }
           if constexpr (!rowLive(k)) return;
           double sc = kNegInf;
           const double d = ldsRead(ldsB, DC_OWN(k));
@@ -633,7 +640,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
           rowEval(kc, d, sc);
         });
         ++rounds;
-        if constexpr (G_ > 1 && DNAS_POLL_SPLIT) loadInbox(IntC<0>{});
+        if constexpr (G_ > 1 && kSplit) loadInbox(IntC<0>{});
         if constexpr (G_ > 1) {
           // the exchange offers of the sweep before have had a sweep to complete: GE may say so now (the wait is for the
           // stragglers, and for this sweep's own offers)
@@ -644,6 +651,8 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
           }
           if (__any(sentX)) pendingBump = true;   // GE is bumped once these offers have completed: in the next sweep
           if (wv == 0 && geNow != geSeen) { geSeen = geNow; changed = 1; }   // import: everybody sweeps once more
+          // confirmation: nothing moved in this sweep -- then the cells loaded IN this sweep must show nothing new either
+          if (!__any(changed)) foldInbox(IntC<0>{});
         }
         if (__any(changed)) {
           // the offers above precede the bump (LDS operations of one wave execute in order)

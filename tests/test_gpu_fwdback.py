@@ -83,23 +83,25 @@ def test_empty_database(da):
 
 
 def test_onchip_and_streaming_kernels_agree(oracle_mod, monkeypatch):
-    """The persistent handle (dnas_fb): the on-chip kernel takes the pairs whose envelope rows are at most 16 cells
-    wide, the streaming kernel the rest; both reproduce the oracle's per-pair log-likelihoods bit for bit, agree
-    with each other on the counts, and a second E-step on the same handle (another model) reuses the database."""
+    """The persistent handle (dnas_fb): the on-chip kernels take the pairs whose envelope rows are at most 16 cells (16 lanes
+    per pair) or 32 cells (32 lanes) wide, the streaming kernel the rest; all reproduce the oracle's per-pair
+    log-likelihoods bit for bit, agree with each other on the counts, and a second E-step on the same handle (another
+    model) reuses the database."""
     import random
     import dnastore_amd as da
     from synth import synthetic_alignment
     O = oracle_mod
     rng = random.Random(21)
     pairs = [O.alignment_pair(synthetic_alignment(rng, rng.choice([1, 7, 33, 100, 256]), sub=.03, dele=.02, dup=.02)) for _ in range(90)]
-    # a pair with a long run of duplications: envelope rows wider than 16 cells -> streaming kernel
+    # pairs with long runs of duplications: envelope rows wider than 16 cells -> the 32-lane kernel; wider than 32 -> streaming
     pairs.append(O.alignment_pair(synthetic_alignment(random.Random(5), 60, sub=.02, dele=.0, dup=.35)))
+    pairs.append(O.alignment_pair(synthetic_alignment(random.Random(6), 90, sub=.02, dele=.0, dup=.8)))
     pk = O.pack_pairs(pairs)
     params = da.MutatorParams.fromFlags()
     fb = da.ForwardBackward(pk)
     counts, ll, per = fb.expectedCounts(params)
     st = fb.stats()
-    assert st["pairs_onchip"] >= 60 and st["pairs_streaming"] >= 1 and st["pairs_onchip"] + st["pairs_streaming"] == len(pairs) and st["lse_ops"] > 0
+    assert st["pairs_onchip"] >= 61 and st["pairs_streaming"] >= 1 and st["pairs_onchip"] + st["pairs_streaming"] == len(pairs) and st["lse_ops"] > 0
     oc, oll, oper = O.expected_counts(O.MutatorParams.from_cli(), pairs)
     assert np.array_equal(per, oper)
     assert np.allclose(counts, oc, rtol=1e-9, atol=1e-300)
