@@ -4,7 +4,7 @@
 #include <stdint.h>
 
 constexpr int kFillThreads = 1024;  // work-group size of viterbi_fill_kernel (16 waves: one work-group fills a CU)
-constexpr int kTraceThreads = 512;  // independent reads per traceback block: a whole batch sits on ONE CU (see runtime.hip)
+constexpr int kTraceThreads = 128;  // independent reads per block of the thread-per-read traceback (see runtime.hip; launch bounds: 1024)
 constexpr int kMaxLen = 32;         // pLen entries (dnas_mutator_params.p_len)
 
 struct DevModel {

@@ -12,15 +12,18 @@
 //   pass 1   Forward over all rows; only the S and D lanes of the last row of every block are kept (a "checkpoint",
 //            2 * W doubles per block, in the slot's scratch): a row is a function of the S and D lanes of the row above
 //            it, because the duplication lanes T only run along a row (fwdback.cpp:57-60).
-//   pass 2   blocks from the last to the first: the block's Forward rows are recomputed from the checkpoint above it;
-//            their S and D lanes stay in LDS (W x W cells x 2), their duplication lanes go to the slot's scratch (read
-//            back one cell per step of the Backward wavefront, long before they are used); then the Backward wavefront
-//            runs up the block -- the row below comes over by shuffle, the block below left its first row in LDS -- and
-//            every finished Backward cell adds its seven posterior terms (fwdback.h:92-112) to the pair's counts.
+//   pass 2   blocks from the last to the first: the block's Forward rows are recomputed from the checkpoint above it and go,
+//            whole (S, D and the duplication lanes of W x W cells), to the slot's scratch; then the Backward wavefront runs up
+//            the block -- the row below comes over by shuffle, the block below left its first row in LDS; the Forward cells a
+//            Backward cell needs (its own, the one to its left, two of the row above) are loaded at the top of its step, long
+//            before the counts use them -- and every finished Backward cell adds its seven posterior terms (fwdback.h:92-112)
+//            to the pair's counts.
 //
-// LDS per pair: 6.3 KB at W = 16 (round 2 kept the duplication lanes and the checkpoints there too: 26 KB), so a CU holds
-// 24 pairs on 6 full waves instead of 6 pairs on 3 half-filled ones.  A work-group is ONE wave (64 / W pairs) and walks the
-// list of pairs with a stride of the grid; nothing in it needs a work-group barrier.
+// LDS per pair: 2 KB at W = 16 (envelope bounds, two boundary rows, the substitution counts; round 2 kept the Forward block
+// and the checkpoints there: 26 KB), so what a CU holds is bounded by registers (128 per lane): 16 waves = 64 pairs instead of
+// 6 pairs on 3 half-filled waves.  A work-group is ONE wave (64 / W pairs) and walks the list of pairs with a stride of the
+// grid; nothing in it needs a work-group barrier.  The kernel waits on memory (the table look-ups of the log-sum-exps come from
+// L2, the Forward cells from L2 / Infinity Cache): pairs per second grew in step with the waves per CU (4.0, 4.9 * 10^5 at 5, 6).
 //
 // The arithmetic of a cell is the reference's, operation for operation (lse() with the reference's 100 001-entry
 // table, uploaded once per handle and L2 resident; the two divisions by the table step are formed with a reciprocal and one
@@ -39,7 +42,7 @@
 namespace {
 
 constexpr double kNegInf = -__builtin_huge_val();
-constexpr int kMaxP = 8;                // duplication lanes this kernel keeps in registers
+// (kMaxP, a template parameter below: the duplication lanes the kernel keeps in registers -- 6 for the CLI's default model, 8 at most)
 
 // x / .0001, correctly rounded, without the division sequence (Markstein: q0 = x * r, e = x - c * q0 exactly, q = q0 + e * r
 // with r the correctly rounded reciprocal); below 1e-280 the residual would underflow: the division itself
@@ -71,7 +74,7 @@ __device__ __forceinline__ double lse(const double* __restrict__ tab, double a, 
 
 // One wave = 64 / W pairs.  pairList[i] = index of the pair in the database; slot scratch: fbOnchipSlotDoubles(W, maxInLen)
 // doubles per pair slot (checkpoints [nCk][W][2], then the duplication lanes of one block [W rows][W cells][8]).
-template <int W>
+template <int W, int kMaxP>
 __device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_t* __restrict__ inSeqs, const int64_t* __restrict__ inOff,
                                                     const int8_t* __restrict__ outSeqs, const int64_t* __restrict__ outOff,
                                                     const int32_t* __restrict__ cmIn, const int64_t* __restrict__ cmInOff,
@@ -81,14 +84,13 @@ __device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_
                                                     unsigned long long* __restrict__ lseOps, double* __restrict__ scratch) {
   extern __shared__ double fbLds[];
   constexpr int PPG = 64 / W;                                       // pairs per wave
-  constexpr int kRS = W * 2 + 2;                                    // doubles per Forward row in LDS (padded against bank conflicts)
+  constexpr int kCell = 2 + kMaxP;                                  // doubles per Forward cell in the slot's scratch: S, D, T[0..7]
   const int g = threadIdx.x / W, l = threadIdx.x % W;
   const int P = a.P, Dm = a.maxDistance;
   const int nCk = (maxInLen + 1 + W - 1) / W;                       // blocks (and checkpoints) of the longest pair
   // LDS of this pair
   double* const base = fbLds + (size_t)g * fbOnchipPairDoubles(W, maxInLen);
-  double* const FB = base;                                           // [W rows][kRS]: (cell j)*2 + {S, D}
-  double* const CKROW = FB + W * kRS;                                // [W cells][2]: the checkpoint row above the block
+  double* const CKROW = base;                                        // [W cells][2]: the checkpoint row above the block
   double* const BRROW = CKROW + W * 2;                               // [2][W cells][2]: Backward S/D of the first row of the block below
   double* const SUBC = BRROW + 2 * W * 2;                            // [16] substitution counts
   double* const SUBS_ = SUBC + 16;                                   // [16] the substitution scores
@@ -98,7 +100,7 @@ __device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_
   // scratch of this slot
   double* const slot = scratch + ((size_t)blockIdx.x * PPG + g) * fbOnchipSlotDoubles(W, maxInLen);
   double* const CK = slot;                                           // [nCk][W cells][2]
-  double* const TB = slot + (size_t)nCk * W * 2;                     // [W rows][W cells][kMaxP]
+  double* const FB = slot + (size_t)nCk * W * 2;                     // [W rows][W cells][kCell]: the Forward cells of the current block
   if (l < 16) SUBS_[l] = a.sub[l];
   if (l < kMaxP) LENS_[l] = a.len[l];
   unsigned long long nLse = 0;
@@ -245,16 +247,15 @@ __device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_
           double s, d;
           forwardCell(ip, op, hasIns, dS, dIn, uS, uD, uIn, s, d);
           curS = s; curD = d;
-          double* cell = FB + l * kRS + (op - lo) * 2;
+          double* cell = FB + ((size_t)l * W + (op - lo)) * kCell;
           cell[0] = s;
           cell[1] = d;
-          double* tb = TB + ((size_t)l * W + (op - lo)) * kMaxP;
 #pragma unroll
-          for (int k = 0; k < kMaxP; ++k) if (k < P) tb[k] = T[k];
+          for (int k = 0; k < kMaxP; ++k) if (k < P) cell[2 + k] = T[k];
         }
       }
     }
-    __threadfence_block();                                         // TB is read back by the same lane, FB by its neighbours
+    __threadfence_block();                                         // the Forward cells are read back by this lane and the one above it
     WAVE_SYNC();
     // ---- Backward of the block (fwdback.cpp:80-116), anti-diagonals downwards, with the counts
     {
@@ -264,7 +265,8 @@ __device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_
       const double* const downRow = BRROW + (size_t)((b + 1) & 1) * W * 2;   // the first row of the block below, left by its lane 0
       double* const mineRow = BRROW + (size_t)(b & 1) * W * 2;               // where this block's lane 0 leaves its row
       const bool lastLane = l == W - 1;
-      const double* upF = l == 0 ? CKROW : FB + (l - 1) * kRS;
+      const double* upF = l == 0 ? CKROW : FB + (size_t)(l - 1) * W * kCell;   // the Forward cells of the row above
+      const int upStride = l == 0 ? 2 : kCell;
       double bcurS = kNegInf, bcurD = kNegInf, bprevS = kNegInf;   // Backward cell of the step before, S of the one before that
       for (int aNow = aFirst; __any(on && aNow >= aEnd); --aNow) {
         const int above = l < W - 1 ? l + 1 : l;
@@ -276,11 +278,17 @@ __device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_
           // the Forward duplication lanes of the cell to the left, (ip, op-1): on their way while the Backward cell is computed
           double ft[kMaxP];
           const bool fIns = op - 1 >= lo;
+          const double* fc = FB + ((size_t)l * W + j) * kCell;     // Forward cell (ip, op): S, D, T[]; fc - kCell: (ip, op-1)
           {
-            const double* tb = TB + ((size_t)l * W + (fIns ? j - 1 : 0)) * kMaxP;
+            const double* tb = fc - (fIns ? kCell : 0) + 2;
 #pragma unroll
             for (int k = 0; k < kMaxP; ++k) ft[k] = (k < P && fIns) ? tb[k] : kNegInf;
           }
+          // ... and the Forward cells of the row above that the counts of this cell look at
+          const bool upD = ip > 0 && op > 0 && inRow(ip - 1, op - 1), upU = ip > 0 && inRow(ip - 1, op);
+          const double fUpDiagS = upD ? upF[(op - 1 - loUp) * upStride] : kNegInf;
+          const double fUpS = upU ? upF[(op - loUp) * upStride] : kNegInf, fUpD = upU ? upF[(op - loUp) * upStride + 1] : kNegInf;
+          const double fOwnS = fc[0], fOwnD = fc[1];
           double s = (ip == I && op == O) ? 0. : kNegInf, d = kNegInf;
           const bool hasIns = op < O && ip > 0 && op + 1 <= hi;    // (ip, op+1) in range: T[] and leftS are that cell's
           const bool sIn = op < O && ip < I && op + 1 >= nlo && op + 1 <= nhi, dInB = ip < I && op >= nlo && op <= nhi;
@@ -310,10 +318,8 @@ __device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_
           leftS = s;
 
           // ---- posterior counts at (ip, op) (fwdback.h:92-112)
-          const double* fc = FB + l * kRS + j * 2;                 // Forward cell (ip, op): S, D
           if (ip > 0 && op > 0) {
-            const double fS = inRow(ip - 1, op - 1) ? upF[(op - 1 - loUp) * 2] : kNegInf;
-            const double cS = exp(fS + a.noGap + SUBS(ip, op) + s - ll);                           // pS2S
+            const double cS = exp(fUpDiagS + a.noGap + SUBS(ip, op) + s - ll);                     // pS2S
             c2 += cS;
             double subAdd = cS;
 #pragma unroll
@@ -324,13 +330,11 @@ __device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_
             atomicAdd(&SUBC[in[ip - 1] * 4 + out[op - 1]], subAdd);
           }
           if (ip > 0) {
-            const bool uIn = inRow(ip - 1, op);
-            const double uS = uIn ? upF[(op - loUp) * 2] : kNegInf, uD = uIn ? upF[(op - loUp) * 2 + 1] : kNegInf;
-            c0 += exp(uS + a.delOpen + d - ll);                                                    // pS2D
-            c3 += exp(uD + a.delExtend + d - ll);                                                  // pD2D
+            c0 += exp(fUpS + a.delOpen + d - ll);                                                  // pS2D
+            c3 += exp(fUpD + a.delExtend + d - ll);                                                // pD2D
           }
-          c4 += exp(fc[1] + a.delEnd + s - ll);                                                    // pD2S
-          const double fs = fc[0];
+          c4 += exp(fOwnD + a.delEnd + s - ll);                                                    // pD2S
+          const double fs = fOwnS;
 #pragma unroll
           for (int k = 0; k < kMaxP; ++k)
             if (k < mdl) {
@@ -374,15 +378,20 @@ __device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_
 
 }  // namespace
 
-#define FB_KERNEL(name, W)                                                                                                        \
-  extern "C" __global__ void __launch_bounds__(64)                                                                                \
+#ifndef DNAS_FB_MIN_WAVES
+#define DNAS_FB_MIN_WAVES 3      // waves per SIMD the register allocation leaves room for: the cell lives in ~235 registers; at 168 it spills 68 of them, and 12 waves per CU still run 1.34 x faster than 8 without spills (the kernel waits on memory)
+#endif
+#define FB_KERNEL(name, W, MP)                                                                                                    \
+  extern "C" __global__ void __launch_bounds__(64, DNAS_FB_MIN_WAVES)                                                             \
   name(FbArgs a, const int8_t* __restrict__ inSeqs, const int64_t* __restrict__ inOff, const int8_t* __restrict__ outSeqs,        \
        const int64_t* __restrict__ outOff, const int32_t* __restrict__ cmIn, const int64_t* __restrict__ cmInOff,                 \
        const int32_t* __restrict__ cmOut, const int64_t* __restrict__ cmOutOff, const double* __restrict__ lseTab,                \
        const int64_t* __restrict__ pairList, int64_t nList, double* __restrict__ pairCounts, double* __restrict__ pairLL,         \
        int maxInLen, unsigned long long* __restrict__ lseOps, double* __restrict__ scratch) {                                     \
-    fwdback_onchip_body<W>(a, inSeqs, inOff, outSeqs, outOff, cmIn, cmInOff, cmOut, cmOutOff, lseTab, pairList, nList, pairCounts, \
+    fwdback_onchip_body<W, MP>(a, inSeqs, inOff, outSeqs, outOff, cmIn, cmInOff, cmOut, cmOutOff, lseTab, pairList, nList, pairCounts, \
                            pairLL, maxInLen, lseOps, scratch);                                                                    \
   }
-FB_KERNEL(fwdback_onchip16_kernel, 16)
-FB_KERNEL(fwdback_onchip32_kernel, 32)
+FB_KERNEL(fwdback_onchip16_kernel, 16, 8)
+FB_KERNEL(fwdback_onchip32_kernel, 32, 8)
+FB_KERNEL(fwdback_onchip16p6_kernel, 16, 6)
+FB_KERNEL(fwdback_onchip32p6_kernel, 32, 6)

@@ -23,6 +23,8 @@ extern "C" __global__ void fwdback_estep_kernel(FbArgs, const int8_t*, const int
                        const int64_t*, const double*, const int64_t*, int64_t, double*, double*, int, unsigned long long*, double*
 extern "C" __global__ void fwdback_onchip16_kernel(FB_ONCHIP_ARGS);
 extern "C" __global__ void fwdback_onchip32_kernel(FB_ONCHIP_ARGS);
+extern "C" __global__ void fwdback_onchip16p6_kernel(FB_ONCHIP_ARGS);     // ... with up to 6 duplication lengths (the CLI's default model) in registers
+extern "C" __global__ void fwdback_onchip32p6_kernel(FB_ONCHIP_ARGS);
 extern "C" __global__ void fwdback_reduce_kernel(const double*, const double*, int64_t, int, double*);
 
 #define HIP_TRY(expr)                                                                          \
@@ -33,6 +35,10 @@ extern "C" __global__ void fwdback_reduce_kernel(const double*, const double*, i
       return dnas::fail(DNAS_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));     \
     }                                                                                          \
   } while (0)
+
+#ifndef DNAS_FB_WAVES_PER_CU
+#define DNAS_FB_WAVES_PER_CU 12     // 4 SIMDs x DNAS_FB_MIN_WAVES of fwdback_onchip.hip
+#endif
 
 namespace {
 
@@ -288,7 +294,8 @@ extern "C" int dnas_fb_estep(dnas_fb* h, const dnas_mutator_params* p, int stric
     const int W = 16 << w, ppg = kFbWave / W;
     const size_t lds = (size_t)ppg * fbOnchipPairDoubles(W, rt.maxInOnchip[w]) * sizeof(double);   // <= kFbOnchipLdsLimit by the routing
     const int64_t nL = (int64_t)rt.onchip[w].size();
-    const int perCu = std::max(1, std::min(8, (int)((size_t)(150 * 1024) / lds)));
+    // work-groups (= waves) a CU holds: 160 KB of LDS, and 16 waves of the kernel's 128 registers per lane
+    const int perCu = std::max(1, std::min(DNAS_FB_WAVES_PER_CU, (int)((size_t)(160 * 1024) / lds)));
     const unsigned grid = (unsigned)std::min<int64_t>((nL + ppg - 1) / ppg, (int64_t)h->cus * perCu);
     const size_t need = (size_t)grid * ppg * fbOnchipSlotDoubles(W, rt.maxInOnchip[w]) * sizeof(double);
     if (need > h->scratchBytes) {
@@ -297,7 +304,8 @@ extern "C" int dnas_fb_estep(dnas_fb* h, const dnas_mutator_params* p, int stric
       HIP_TRY(hipMalloc((void**)&h->dScratch, need));
       h->scratchBytes = need;
     }
-    hipLaunchKernelGGL(w == 0 ? fwdback_onchip16_kernel : fwdback_onchip32_kernel, dim3(grid), dim3(kFbWave), lds, h->stream, a, h->dIn, h->dInOff,
+    auto kernel = P <= 6 ? (w == 0 ? fwdback_onchip16p6_kernel : fwdback_onchip32p6_kernel) : (w == 0 ? fwdback_onchip16_kernel : fwdback_onchip32_kernel);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kFbWave), lds, h->stream, a, h->dIn, h->dInOff,
                        h->dOut, h->dOutOff, h->dCi, h->dCiOff, h->dCo, h->dCoOff, h->dTab, rt.dOnchip[w], nL, h->dCounts, h->dLL, rt.maxInOnchip[w],
                        h->dLseOps, h->dScratch);
     HIP_TRY(hipGetLastError());

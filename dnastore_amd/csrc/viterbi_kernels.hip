@@ -279,7 +279,7 @@ viterbi_fill_kernel(DevModel m, const uint8_t* __restrict__ bases, const uint64_
 
 // One thread per read: the reference's sequential pointer chase, candidate order and
 // strict '>' tie-breaking included (viterbi.cpp:217-228,247-301).
-extern "C" __global__ void __launch_bounds__(kTraceThreads)
+extern "C" __global__ void __launch_bounds__(1024)
 viterbi_traceback_kernel(DevModel m, const uint8_t* __restrict__ bases, const uint64_t* __restrict__ readOff,
                          const int32_t* __restrict__ batchRead, const uint64_t* __restrict__ slotOff,
                          const double* __restrict__ arena, char* __restrict__ outSym,

@@ -128,7 +128,7 @@ def test_one_long_pair_does_not_fail_the_database(oracle_mod):
     from synth import synthetic_alignment
     O = oracle_mod
     rng = random.Random(8)
-    pairs = [O.alignment_pair(synthetic_alignment(rng, n, sub=.02, dele=.01, dup=.01)) for n in (40, 256, 4000, 130)]
+    pairs = [O.alignment_pair(synthetic_alignment(rng, n, sub=.02, dele=.01, dup=.01)) for n in (40, 256, 4000, 12000, 130)]
     fb = da.ForwardBackward(O.pack_pairs(pairs))
     counts, ll, per = fb.expectedCounts(da.MutatorParams.fromFlags())
     st = fb.stats()
