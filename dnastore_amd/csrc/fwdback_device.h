@@ -10,14 +10,13 @@ constexpr int kFbMaxCounts = 21 + kFbMaxLen;
 // on-chip kernels (fwdback_onchip.hip): W = 16 or 32 lanes per pair (the widest envelope row served), a wave per work-group
 constexpr int kFbWave = 64;
 constexpr size_t kFbOnchipLdsLimit = 64 * 1024;   // dynamic LDS a work-group of the on-chip kernel may ask for (several fit a CU)
-// doubles of LDS one pair needs there: the checkpoint row above the block [W][2], the Backward row of the block below [2][W][2],
-// substitution counts and scores [16 + 16], length scores [8], envelope bounds as int16
+// doubles of LDS one pair needs there: substitution counts and scores [16 + 16], length scores [8], envelope bounds as int16
 __host__ __device__ constexpr size_t fbOnchipPairDoubles(int W, int maxInLen) {
-  return (size_t)W * 2 + (size_t)W * 4 + 16 + 16 + 8 + ((size_t)(maxInLen + 2) * 2 * sizeof(short) + 7) / 8 + 1;
+  return 16 + 16 + 8 + ((size_t)(maxInLen + 2) * 2 * sizeof(short) + 7) / 8 + 1;
 }
-// doubles of global scratch per pair slot: the checkpoints [blocks][W][2] and the Forward cells of one block [W][W][2 + 8]
+// doubles of global scratch per pair slot: the Forward cells of the pair, [maxInLen + 1 rows][W cells][S, D, T[0..7]]
 __host__ __device__ constexpr size_t fbOnchipSlotDoubles(int W, int maxInLen) {
-  return (size_t)((maxInLen + 1 + W - 1) / W) * W * 2 + (size_t)W * W * 10;
+  return (size_t)(maxInLen + 1) * W * 10;
 }
 
 struct FbArgs {

@@ -54,26 +54,36 @@ __device__ __forceinline__ double divStep(double x) {
   return __builtin_fma(e, r, q0);
 }
 
-__device__ __forceinline__ double lse_unary(const double* __restrict__ tab, double x) {
-  if (x >= 10. || x != x || x == __builtin_huge_val()) return 0;   // logsumexp.h:41-42
-  if (x < 0) return -x;
-  const int n = (int)divStep(x);                  // (int)(x / .0001)
-  const double dx = x - (n * .0001);
-  const double f0 = tab[n], f1 = tab[n + 1];
-  const double df = f1 - f0;
-  return f0 + df * divStep(dx);                   // f0 + df * (dx / .0001)
+// The reference's log(1 + exp(-x)) (logsumexp.h:38-54): 0 for x >= 10 (and for the +inf / NaN that a difference of -inf's
+// gives), else the table value at n = (int)(x / .0001) interpolated to x.  Written without branches: a lane whose x is out
+// of range looks up entry 0 and throws the result away.  The table is read the buffer way (base in scalar registers, one
+// 16-byte load for the two neighbouring entries: no 64-bit address arithmetic per look-up).
+typedef __amdgpu_buffer_rsrc_t fb_rsrc_t;
+typedef unsigned fb_u32x4 __attribute__((ext_vector_type(4)));
+typedef double fb_dbl2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double lse_unary(fb_rsrc_t tab, double x) {
+  const bool in = x < 10.;                        // false for NaN and +inf as well (logsumexp.h:41-42); x is never negative here
+  const double xs = in ? x : 0.;
+  const int n = (int)divStep(xs);                 // (int)(x / .0001)
+  const double dx = xs - (n * .0001);
+  const fb_dbl2 f = __builtin_bit_cast(fb_dbl2, __builtin_amdgcn_raw_buffer_load_b128(tab, n * 8, 0, 0));   // tab[n], tab[n + 1]
+  const double df = f.y - f.x;
+  const double v = f.x + df * divStep(dx);        // f0 + df * (dx / .0001)
+  return in ? v : 0.;
 }
 
-__device__ __forceinline__ double lse(const double* __restrict__ tab, double a, double b) {   // logsumexp.h:56-74
-  double mx, diff;
-  if (a == b) { mx = a; diff = 0; }
-  else if (a < b) { mx = b; diff = b - a; }
-  else { mx = a; diff = a - b; }
-  return mx + lse_unary(tab, diff);
+// log_sum_exp (logsumexp.h:56-74): max + f(|a - b|).  The reference takes a == b apart to avoid (-inf) - (-inf); here that
+// difference is NaN, for which f is 0 like for every x >= 10, so the three cases fold into max / min / one subtraction
+// (b - a and a - b are the same number as max - min).
+__device__ __forceinline__ double lse(fb_rsrc_t tab, double a, double b) {
+  double mx, mn;       // (the instructions themselves: no NaN comes in, so the canonicalising copies around fmax / fmin are waste)
+  asm("v_max_f64 %0, %1, %2" : "=v"(mx) : "v"(a), "v"(b));
+  asm("v_min_f64 %0, %1, %2" : "=v"(mn) : "v"(a), "v"(b));
+  return mx + lse_unary(tab, mx - mn);
 }
 
 // One wave = 64 / W pairs.  pairList[i] = index of the pair in the database; slot scratch: fbOnchipSlotDoubles(W, maxInLen)
-// doubles per pair slot (checkpoints [nCk][W][2], then the duplication lanes of one block [W rows][W cells][8]).
+// doubles per pair slot: the Forward cells of the pair, [row][W cells][S, D, T[0..7]].
 template <int W, int kMaxP>
 __device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_t* __restrict__ inSeqs, const int64_t* __restrict__ inOff,
                                                     const int8_t* __restrict__ outSeqs, const int64_t* __restrict__ outOff,
@@ -84,27 +94,23 @@ __device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_
                                                     unsigned long long* __restrict__ lseOps, double* __restrict__ scratch) {
   extern __shared__ double fbLds[];
   constexpr int PPG = 64 / W;                                       // pairs per wave
-  constexpr int kCell = 2 + kMaxP;                                  // doubles per Forward cell in the slot's scratch: S, D, T[0..7]
+  constexpr int kCell = 10;                                         // doubles per Forward cell in the slot's scratch: S, D, T[0..7]
   const int g = threadIdx.x / W, l = threadIdx.x % W;
   const int P = a.P, Dm = a.maxDistance;
-  const int nCk = (maxInLen + 1 + W - 1) / W;                       // blocks (and checkpoints) of the longest pair
   // LDS of this pair
   double* const base = fbLds + (size_t)g * fbOnchipPairDoubles(W, maxInLen);
-  double* const CKROW = base;                                        // [W cells][2]: the checkpoint row above the block
-  double* const BRROW = CKROW + W * 2;                               // [2][W cells][2]: Backward S/D of the first row of the block below
-  double* const SUBC = BRROW + 2 * W * 2;                            // [16] substitution counts
+  double* const SUBC = base;                                         // [16] substitution counts
   double* const SUBS_ = SUBC + 16;                                   // [16] the substitution scores
-  double* const LENS_ = SUBS_ + 16;                                  // [kMaxP]
-  short* const LO = reinterpret_cast<short*>(LENS_ + kMaxP);         // [maxInLen + 2]
+  double* const LENS_ = SUBS_ + 16;                                  // [8]
+  short* const LO = reinterpret_cast<short*>(LENS_ + 8);             // [maxInLen + 2]
   short* const HI = LO + (maxInLen + 2);
-  // scratch of this slot
-  double* const slot = scratch + ((size_t)blockIdx.x * PPG + g) * fbOnchipSlotDoubles(W, maxInLen);
-  double* const CK = slot;                                           // [nCk][W cells][2]
-  double* const FB = slot + (size_t)nCk * W * 2;                     // [W rows][W cells][kCell]: the Forward cells of the current block
+  // scratch of this slot: every Forward cell of the pair
+  double* const FW = scratch + ((size_t)blockIdx.x * PPG + g) * fbOnchipSlotDoubles(W, maxInLen);
   if (l < 16) SUBS_[l] = a.sub[l];
   if (l < kMaxP) LENS_[l] = a.len[l];
   unsigned long long nLse = 0;
-#define LSE(x, y) (++nLse, lse(lseTab, (x), (y)))
+  const fb_rsrc_t lseRsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(lseTab), 0, 100001 * 8, 0x00020000);
+#define LSE(x, y) (++nLse, lse(lseRsrc, (x), (y)))
 #define SUBS(i, o) SUBS_[in[(i) - 1] * 4 + out[(o) - 1]]                 /* cellSubScore, fwdback.h:65-67 */
 #define DUPS(i, o, k) SUBS_[in[(i) - 1 - (k)] * 4 + out[(o) - 1]]        /* cellTanDupScore, fwdback.h:69-71 */
 #define WAVE_SYNC() __builtin_amdgcn_wave_barrier()                      /* LDS traffic of one wave is in order: a compiler fence */
@@ -137,7 +143,6 @@ __device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_
   }
   WAVE_SYNC();
 
-  const int nBlocks = live ? (I + 1 + W - 1) / W : 0;
   double ll = kNegInf;
   double T[kMaxP];                                                 // duplication lanes of this lane's previous cell
   double leftS = kNegInf;                                          // (Backward: S of the previous cell of the row)
@@ -171,8 +176,8 @@ __device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_
   // is (row r, column op) inside the envelope
   auto inRow = [&](int r, int op) -> bool { return r >= 0 && r <= I && op >= LO[r] && op <= HI[r]; };
 
-  // ---------------- pass 1: Forward, checkpoints only.  What the lane below computed one and two steps ago is this lane's
-  // (ip-1, op) and (ip-1, op-1): the steps are global (a = ip + op), every cell has its one step
+  // ---------------- pass 1: Forward (fwdback.cpp:43-78), every cell to the slot's scratch.  What the lane below computed one and
+  // two steps ago is this lane's (ip-1, op) and (ip-1, op-1): the steps are global (a = ip + op), every cell has its one step
   {
     int ip = l;                                                    // this lane's row
     int aNow = live ? LO[0] : 0;                                   // global step = ip + op
@@ -191,13 +196,13 @@ __device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_
           double s, d;
           forwardCell(ip, op, hasIns, dS, dIn, uS, uD, uIn, s, d);
           curS = s; curD = d;
-          if (ip % W == W - 1 || ip == I) {                        // the block's last row is its checkpoint
-            double* ck = CK + ((size_t)(ip / W) * W + (op - lo)) * 2;
-            ck[0] = s;
-            ck[1] = d;
-          }
+          double* cell = FW + ((size_t)ip * W + (op - lo)) * kCell;
+          cell[0] = s;
+          cell[1] = d;
+#pragma unroll
+          for (int k = 0; k < kMaxP; ++k) if (k < P) cell[2 + k] = T[k];
           if (ip == I && op == O) ll = s;                          // loglike = sCell(inLen, outLen), fwdback.cpp:76
-          if (op == hi) ip += W;                                   // row done: on to this lane's row of the next block
+          if (op == hi) ip += W;                                   // row done: on to this lane's next row
         } else if (op > hi) {
           ip += W;                                                 // (an empty row)
         }
@@ -207,95 +212,49 @@ __device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_
   // every lane of the pair needs the log-likelihood; the lane that owned (I, O) has it
   for (int offs = W / 2; offs > 0; offs >>= 1) { const double o2 = __shfl_xor(ll, offs, W); ll = ll < o2 ? o2 : ll; }
   if (live && l == 0) pairLL[pair] = ll;
-  __threadfence_block();                                           // the checkpoints are read back by other lanes of this wave
+  __threadfence_block();                                           // the Forward cells are read back by this lane and the one above it
+  WAVE_SYNC();
 
-  // ---------------- pass 2: per block, Forward again (S and D kept in LDS, T in the slot's scratch), then Backward + counts
+  // ---------------- pass 2: Backward (fwdback.cpp:80-116), anti-diagonals downwards, with the counts.  The row below (ip+1)
+  // belongs to the lane above: its cells (ip+1, op+1) and (ip+1, op) were finished two steps and one step ago
   double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, cl[kMaxP];
 #pragma unroll
   for (int k = 0; k < kMaxP; ++k) cl[k] = 0;
-  for (int b = nBlocks - 1; __any(b >= 0); --b) {
-    const bool on = live && b >= 0;
-    const int r0 = b * W, rLast = on ? (r0 + W - 1 < I ? r0 + W - 1 : I) : -1;
-    const int ip = r0 + l;
-    const bool mine = on && ip <= rLast;
-    const int lo = mine ? LO[ip] : 0, hi = mine ? HI[ip] : -1;
-    // the checkpoint row above the block, from the scratch into LDS (a cell per lane)
-    WAVE_SYNC();
-    if (on && b > 0) {
-      const double* ck = CK + ((size_t)(b - 1) * W + l) * 2;
-      CKROW[l * 2] = ck[0];
-      CKROW[l * 2 + 1] = ck[1];
-    }
-    WAVE_SYNC();
-    const int loUp = (on && ip > 0 && ip - 1 <= I) ? LO[ip - 1] : 0;
-    // ---- Forward of the block
-    {
-      const int aFirst = on ? r0 + LO[r0] : 0, aEnd = on ? rLast + HI[rLast] : -1;
-      double curS = kNegInf, curD = kNegInf, prevS = kNegInf;
-      for (int aNow = aFirst; __any(on && aNow <= aEnd); ++aNow) {
-        const int below = l > 0 ? l - 1 : 0;
-        double uS = FROM_LANE(curS, below), uD = FROM_LANE(curD, below), dS = FROM_LANE(prevS, below);
-        prevS = curS;
+  {
+    int ip = (live && l <= I) ? l + ((I - l) / W) * W : -1;        // this lane's last row
+    const int aFirst = live ? I + HI[I] : -1, aEnd = live ? LO[0] : 0;
+    double bcurS = kNegInf, bcurD = kNegInf, bprevS = kNegInf;     // Backward cell of the step before, S of the one before that
+    for (int aNow = aFirst; __any(live && aNow >= aEnd); --aNow) {
+      const int above = (l + 1) % W;                               // (lane W-1 follows lane 0: its row W*b - 1 comes after row W*b)
+      const double nS = FROM_LANE(bprevS, above), nD = FROM_LANE(bcurD, above);   // (ip+1, op+1).S and (ip+1, op).D
+      bprevS = bcurS;
+      if (live && ip >= 0) {
+        const int lo = LO[ip], hi = HI[ip];
         const int op = aNow - ip;
-        if (mine && op >= lo && op <= hi) {
-          const bool hasIns = ip > 0 && op > 0 && op - 1 >= lo;
-          const bool dIn = ip > 0 && op > 0 && inRow(ip - 1, op - 1), uIn = ip > 0 && inRow(ip - 1, op);
-          if (l == 0) {                                            // the row above is the checkpoint
-            if (dIn) dS = CKROW[(op - 1 - loUp) * 2];
-            if (uIn) { uS = CKROW[(op - loUp) * 2]; uD = CKROW[(op - loUp) * 2 + 1]; }
-          }
-          double s, d;
-          forwardCell(ip, op, hasIns, dS, dIn, uS, uD, uIn, s, d);
-          curS = s; curD = d;
-          double* cell = FB + ((size_t)l * W + (op - lo)) * kCell;
-          cell[0] = s;
-          cell[1] = d;
-#pragma unroll
-          for (int k = 0; k < kMaxP; ++k) if (k < P) cell[2 + k] = T[k];
-        }
-      }
-    }
-    __threadfence_block();                                         // the Forward cells are read back by this lane and the one above it
-    WAVE_SYNC();
-    // ---- Backward of the block (fwdback.cpp:80-116), anti-diagonals downwards, with the counts
-    {
-      const int aFirst = on ? rLast + HI[rLast] : -1, aEnd = on ? r0 + LO[r0] : 0;
-      const int mdl = ip < P ? ip : P;
-      const int nlo = (mine && ip < I) ? LO[ip + 1] : 0, nhi = (mine && ip < I) ? HI[ip + 1] : -1;
-      const double* const downRow = BRROW + (size_t)((b + 1) & 1) * W * 2;   // the first row of the block below, left by its lane 0
-      double* const mineRow = BRROW + (size_t)(b & 1) * W * 2;               // where this block's lane 0 leaves its row
-      const bool lastLane = l == W - 1;
-      const double* upF = l == 0 ? CKROW : FB + (size_t)(l - 1) * W * kCell;   // the Forward cells of the row above
-      const int upStride = l == 0 ? 2 : kCell;
-      double bcurS = kNegInf, bcurD = kNegInf, bprevS = kNegInf;   // Backward cell of the step before, S of the one before that
-      for (int aNow = aFirst; __any(on && aNow >= aEnd); --aNow) {
-        const int above = l < W - 1 ? l + 1 : l;
-        double nS = FROM_LANE(bprevS, above), nD = FROM_LANE(bcurD, above);   // (ip+1, op+1).S and (ip+1, op).D
-        bprevS = bcurS;
-        const int op = aNow - ip;
-        if (mine && op >= lo && op <= hi) {
+        if (op >= lo && op <= hi) {
           const int j = op - lo;
-          // the Forward duplication lanes of the cell to the left, (ip, op-1): on their way while the Backward cell is computed
+          const int mdl = ip < P ? ip : P;
+          const int nlo = ip < I ? LO[ip + 1] : 0, nhi = ip < I ? HI[ip + 1] : -1;
+          const int loUp = ip > 0 ? LO[ip - 1] : 0;
+          // the Forward cells this cell's counts look at -- its own, the duplication lanes of the one to its left, two of the row
+          // above -- are on their way while the Backward cell is computed
+          const double* fc = FW + ((size_t)ip * W + j) * kCell;    // Forward cell (ip, op): S, D, T[]; fc - kCell: (ip, op-1)
+          const double* upF = FW + (size_t)(ip > 0 ? ip - 1 : 0) * W * kCell;
           double ft[kMaxP];
           const bool fIns = op - 1 >= lo;
-          const double* fc = FB + ((size_t)l * W + j) * kCell;     // Forward cell (ip, op): S, D, T[]; fc - kCell: (ip, op-1)
           {
             const double* tb = fc - (fIns ? kCell : 0) + 2;
 #pragma unroll
             for (int k = 0; k < kMaxP; ++k) ft[k] = (k < P && fIns) ? tb[k] : kNegInf;
           }
-          // ... and the Forward cells of the row above that the counts of this cell look at
-          const bool upD = ip > 0 && op > 0 && inRow(ip - 1, op - 1), upU = ip > 0 && inRow(ip - 1, op);
-          const double fUpDiagS = upD ? upF[(op - 1 - loUp) * upStride] : kNegInf;
-          const double fUpS = upU ? upF[(op - loUp) * upStride] : kNegInf, fUpD = upU ? upF[(op - loUp) * upStride + 1] : kNegInf;
+          const bool upDg = ip > 0 && op > 0 && inRow(ip - 1, op - 1), upU = ip > 0 && inRow(ip - 1, op);
+          const double fUpDiagS = upDg ? upF[(size_t)(op - 1 - loUp) * kCell] : kNegInf;
+          const double fUpS = upU ? upF[(size_t)(op - loUp) * kCell] : kNegInf, fUpD = upU ? upF[(size_t)(op - loUp) * kCell + 1] : kNegInf;
           const double fOwnS = fc[0], fOwnD = fc[1];
+
           double s = (ip == I && op == O) ? 0. : kNegInf, d = kNegInf;
           const bool hasIns = op < O && ip > 0 && op + 1 <= hi;    // (ip, op+1) in range: T[] and leftS are that cell's
           const bool sIn = op < O && ip < I && op + 1 >= nlo && op + 1 <= nhi, dInB = ip < I && op >= nlo && op <= nhi;
-          if (lastLane) {                                          // the row below belongs to the block below
-            if (sIn) nS = downRow[(op + 1 - nlo) * 2];
-            if (dInB) nD = downRow[(op - nlo) * 2 + 1];
-          }
           if (sIn) s = a.noGap + SUBS(ip + 1, op + 1) + nS;
           double bt[kMaxP];
 #pragma unroll
@@ -312,7 +271,6 @@ __device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_
           for (int k = 0; k < kMaxP; ++k) if (k < mdl) s = LSE(s, bt[k] + a.tanDup + LENS_[k]);
           d = LSE(d, s + a.delEnd);
           bcurS = s; bcurD = d;
-          if (l == 0) { mineRow[j * 2] = s; mineRow[j * 2 + 1] = d; }
 #pragma unroll
           for (int k = 0; k < kMaxP; ++k) T[k] = bt[k];
           leftS = s;
@@ -342,6 +300,9 @@ __device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_
               c1 += cT;
               cl[k] += cT;
             }
+          if (op == lo) ip -= W;                                   // row done: on to this lane's next row up
+        } else if (op < lo) {
+          ip -= W;                                                 // (an empty row)
         }
       }
     }

@@ -296,8 +296,15 @@ extern "C" int dnas_fb_estep(dnas_fb* h, const dnas_mutator_params* p, int stric
     const int64_t nL = (int64_t)rt.onchip[w].size();
     // work-groups (= waves) a CU holds: 160 KB of LDS, and 16 waves of the kernel's 128 registers per lane
     const int perCu = std::max(1, std::min(DNAS_FB_WAVES_PER_CU, (int)((size_t)(160 * 1024) / lds)));
-    const unsigned grid = (unsigned)std::min<int64_t>((nL + ppg - 1) / ppg, (int64_t)h->cus * perCu);
-    const size_t need = (size_t)grid * ppg * fbOnchipSlotDoubles(W, rt.maxInOnchip[w]) * sizeof(double);
+    // every slot keeps the Forward cells of the pair it works on in HBM (330 KB for a 256-nt pair): the slots of a launch are
+    // bounded by a scratch budget (16 GB, a quarter of what is free) when the inputs are long
+    const size_t slotBytes = fbOnchipSlotDoubles(W, rt.maxInOnchip[w]) * sizeof(double);
+    size_t freeB = 0, totalB = 0;
+    HIP_TRY(hipMemGetInfo(&freeB, &totalB));
+    const size_t budget = std::max<size_t>(h->scratchBytes, std::min<size_t>((size_t)16 << 30, (freeB + h->scratchBytes) / 4));
+    const int64_t slotsMax = std::max<int64_t>(1, (int64_t)(budget / ((size_t)ppg * slotBytes)));
+    const unsigned grid = (unsigned)std::min<int64_t>(std::min<int64_t>((nL + ppg - 1) / ppg, (int64_t)h->cus * perCu), slotsMax);
+    const size_t need = (size_t)grid * ppg * slotBytes;
     if (need > h->scratchBytes) {
       HIP_TRY(hipStreamSynchronize(h->stream));
       if (h->dScratch) { (void)hipFree(h->dScratch); h->dScratch = nullptr; h->scratchBytes = 0; }
