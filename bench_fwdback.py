@@ -5,8 +5,8 @@ default error model (P = 6).  125 000 pairs per GPU by default (1M over 8 GPUs);
 are tiled to that number (making a million alignments in Python would take longer than the measurement).
 
 A "step" is one E-step over the shard with the database resident in HBM (dnas_fb handle: table and pairs uploaded
-once); `value` = read (output) nt per second.  The DP cells live on chip, so HBM only sees inputs and outputs: the
-roofline object reports the bound the kernel is actually under -- the fp64 log-sum-exp rate -- beside the HBM figure.
+once); `value` = read (output) nt per second.  The roofline object reports the bound the kernel is actually under -- fp64
+vector issue (`issue`) -- beside the HBM figure the contract asks for.
 With N > 1 ranks every rank makes its own pairs; the 22+P counts are all-reduced (RCCL) inside the timed region.
 """
 import json
@@ -133,6 +133,22 @@ def fwdback_line(ctx, n_pairs, steps, warmup, cpu_seconds, timed_only):
         P = len(params.pLen)
         in_nt = int(pk["in_off"][-1])
         alg_bytes = (in_nt + nt) + 4 * (in_nt + nt + 2 * n_pairs) + 8 * (22 + P) * n_pairs
+        # What bounds the kernel: not HBM (the algorithmic bytes are the inputs and the counts; the Forward cells it parks in HBM
+        # between its two passes are ~0.6 MB per pair, a tenth of the chip's bandwidth at this rate) but the instruction stream of
+        # the cells -- fp64 vector issue.  The instruction count per pair is a recorded figure (separate rocprofv3 --pmc passes of
+        # this command, profiles/r3_sq_counters_fwdback.json), like `traffic` of the Viterbi lines; peak = one vector instruction per
+        # SIMD every four cycles: 256 CUs x 4 SIMDs x 2.4 GHz / 4.
+        issue = None
+        try:
+            sq = json.load(open(os.path.join(ROOT, "profiles", "r3_sq_counters_fwdback.json")))
+            per_pair = sq["derived"]["valu_per_pair"]
+            peak = 256 * 4 * 2.4e9 / 4
+            ach = per_pair * total_pairs * steps / elapsed / max(world, 1)
+            issue = {"bound": "fp64 vector issue", "achieved": ach, "peak": peak, "unit": "wave instructions/s per GPU", "frac": ach / peak,
+                     "valu_wave_instructions_per_pair": per_pair, "source": "profiles/r3_sq_counters_fwdback.json (SQ_INSTS_VALU of one E-step / pairs)",
+                     "valu_active_share_of_wave_cycles": sq["derived"].get("valu_issue_share_of_wave_cycles")}
+        except (OSError, ValueError, KeyError):
+            pass
         line = {
             "metric": "forward-backward E-step, read nt/sec (whole node)",
             "value": value, "unit": "nt/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -144,10 +160,12 @@ def fwdback_line(ctx, n_pairs, steps, warmup, cpu_seconds, timed_only):
             "pairs_per_s": total_pairs * steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": alg_bytes * steps / (kernel_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg_bytes * steps / (kernel_ms / 1e3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
-                         "kernel": "fwdback_onchip_kernel", "avg_launch_ms": kernel_ms / steps,
+                         "kernel": "fwdback_onchip16p6_kernel", "avg_launch_ms": kernel_ms / steps,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "the DP cells live in LDS: the kernel is bound by the dependent log-sum-exp look-ups of a cell, not by HBM; "
-                                 "lse_ops_per_s is its real rate",
+                         "note": "the algorithmic bytes are inputs and outputs only, so this fraction says nothing: the kernel is bound by the "
+                                 "instruction stream of a cell (log-sum-exp look-ups, fp64 exp) -- see `issue`; lse_ops_per_s is its rate of "
+                                 "log-sum-exp operations",
+                         "issue": issue,
                          "lse_ops_per_s": lse_ops / (kernel_ms / 1e3) if kernel_ms > 0 else 0.0,
                          "pairs_onchip": st["pairs_onchip"], "pairs_streaming": st["pairs_streaming"]},
             "cpu_baseline": cpu,

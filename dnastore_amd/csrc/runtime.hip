@@ -68,6 +68,7 @@ struct TierALaunch {
   unsigned long long timeoutTicks;
   unsigned long long arriveTicks;
   const int* colRange;          // bounded-memory decode: [nReads][2] first and last column of this launch (null: whole reads)
+  int spread;                   // tier C: 1 = a cluster's members are neighbouring blocks (spread over the XCDs; option cluster_spread, tests)
 };
 
 struct dnas_model {
@@ -90,6 +91,7 @@ struct dnas_model {
   unsigned* dFoldTab = nullptr; // tier C: inbox slot -> LDS cells, per member
   size_t xStride = 0;           // doubles per cluster in dXbuf
   unsigned long long timeoutTicks = 0, arriveTicks = 0;
+  int clusterSpread = 0;        // option cluster_spread=1: members of a cluster on different XCDs (a test of the protocol, slower)
   unsigned* syncCheck = nullptr;     // pinned host copies of the sync blocks of every launch of the last call (watchdog, placement census)
   size_t syncCheckWords = 0, syncCheckCap = 0;
   size_t syncLaunches = 0;
@@ -510,6 +512,7 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
             double arrive = 60.0;   // ... and for the work-groups of a cluster to have all been started (CUs held by others)
             if (const char* s = opt("cluster_arrive_s")) arrive = std::max(0.001, atof(s));
             m->arriveTicks = (unsigned long long)(arrive * 1e8);
+            if (const char* s = opt("cluster_spread")) m->clusterSpread = atoi(s) != 0;
             m->tier = 2;
             m->tierNote = "tier C: " + std::to_string(p.G) + " work-groups per read, " + std::to_string(m->maxClusters) +
                           " clusters, exchange edges " + std::to_string(p.crossEdges) + ", " + p.key + "; " + recordNote;
@@ -753,7 +756,7 @@ struct FillLauncher {
       return DNAS_OK;
     }
     TierALaunch la{m->argsA, m->dEntTab, m->dMetaTab, d_bases, m->dReadOff, batchRead, slots,
-                   m->arena, d_out_loglike, m->dRounds, nullptr, nullptr, nullptr, 0, nB, 0ull, 0ull, colRange};
+                   m->arena, d_out_loglike, m->dRounds, nullptr, nullptr, nullptr, 0, nB, 0ull, 0ull, colRange, m->clusterSpread};
     unsigned grid = (unsigned)nB;
     int nClusters = 0;
     if (m->tier == 2) {
@@ -763,7 +766,7 @@ struct FillLauncher {
       const int G = m->plan.G;
       nClusters = std::min(nB, m->maxClusters);
       la.xbuf = m->dXbuf; la.syncWords = m->dSync; la.foldTab = m->dFoldTab; la.nClusters = nClusters; la.timeoutTicks = m->timeoutTicks; la.arriveTicks = m->arriveTicks;
-      grid = (unsigned)(8 * G * ((nClusters + 7) / 8));
+      grid = m->clusterSpread ? (unsigned)(G * nClusters) : (unsigned)(8 * G * ((nClusters + 7) / 8));
       const size_t nX = m->xStride * (size_t)nClusters;
       hipLaunchKernelGGL(fill_neginf_kernel, dim3((unsigned)((nX + 255) / 256)), dim3(256), 0, m->stream, m->dXbuf, nX);
       HIP_TRY(hipGetLastError());

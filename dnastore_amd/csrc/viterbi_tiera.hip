@@ -25,16 +25,20 @@
 // owns a part of the states (host/plan.cpp cuts the machine along its depth-first walk).  Edges inside a
 // member work as above.  A state with an in-edge from another member also owns a slot of its member's
 // INBOX in the cluster's exchange buffer in global memory: the other members offer into it with
-// global_atomic_max_f64, and thread t of the owner folds slot r*T + t into the state's LDS accumulators
-// once per sweep (agent-scope loads issued at the start of the sweep, ds_max at its end), so the protocol
-// is correct wherever the work-groups run; the launcher places a cluster on one XCD (blockIdx b and b+8
-// share one) for speed only.  Termination is
-// agreed in two levels: inside a work-group as before, across the cluster through a device-scope epoch
-// GE (bumped after every batch of exchange offers has completed) and one idle word per member.
+// an agent-scope atomic max, and thread t of the owner folds slot r*T + t into the state's LDS accumulators
+// once per sweep (sc1 loads issued behind the last row of a sweep, ds_max in front of the first row of the next),
+// so the protocol is correct wherever the work-groups run; the launcher places a cluster on one XCD (blockIdx
+// b and b+8 share one) for speed only.  Termination is agreed in two levels: inside a work-group as before,
+// across the cluster through a device-scope epoch GE (bumped after every batch of exchange offers has
+// completed) and one idle word per member.
+//
+// Global memory -- tables, lattice columns, exchange buffer -- is addressed the buffer way (descriptor in scalar
+// registers + 32-bit lane offset): no specialisation of this file keeps a pointer in vector registers or spills.
 //
 // Compile-time parameters (-D):  DNAS_T threads, DNAS_K rows, DNAS_D dup lanes,
 //   DNAS_NS slots per member (= K*T), DNAS_SROWS S stripes, DNAS_NCLS distinct edge scores,
 //   DNAS_G members per cluster, DNAS_GROWS inbox slots per thread, the first DNAS_GSROWS of them with an S cell,
+//   DNAS_POLLS (tier C, optional) how a sweep looks into the inbox, DNAS_SEGMENTS=1 the bounded-memory build,
 //   DNAS_ROWS  brace list of {out-edge entries (-1: row left empty), S stripe or -1, kind, cls, full, gOut}
 //              per row; what all entries of a row have in common is not decoded per lane.
 #ifndef __HIPCC_RTC__
@@ -221,7 +225,8 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
                    double* __restrict__ xbuf, unsigned* __restrict__ syncWords, const unsigned* __restrict__ foldTab,   // [G][GROWS][T]
                    int nClusters, int nReads, unsigned long long timeoutTicks,   // watchdog per lattice column (100 MHz ticks)
                    unsigned long long arriveTicks,    // ... and for the members of a cluster to have all started
-                   const int* __restrict__ colRange) {   // [nReads][2] first and last column to fill, or null: 0 .. L
+                   const int* __restrict__ colRange,     // [nReads][2] first and last column to fill, or null: 0 .. L
+                   int spread) {                         // tier C, tests: 1 = the members of a cluster are NEIGHBOURING blocks (different XCDs)
   extern __shared__ double lds[];
   extern __shared__ unsigned ldsU[];
   constexpr int T = DNAS_T, K = DNAS_K, D_ = DNAS_D, lanes = 2, NSm = DNAS_NS, NS = DNAS_NS * DNAS_G;   // stored lanes: S, D
@@ -244,9 +249,11 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
   const double* xBase = xbuf;  // this cluster's exchange buffer
   unsigned* SY = nullptr;      // this cluster's sync block
   if constexpr (G_ > 1) {
+    // (spread: block b is member b % G of cluster b / G -- consecutive blocks go to different XCDs, so every cluster is split
+    //  over several; the protocol does not care, only the exchange is slower: tests/test_gpu_tier_c.py)
     const int b = (int)blockIdx.x, q = b >> 3;
-    member = q % G_;
-    const int cluster = (q / G_) * 8 + (b & 7);
+    member = spread ? b % G_ : q % G_;
+    const int cluster = spread ? b / G_ : (q / G_) * 8 + (b & 7);
     if (cluster >= nClusters) return;
     rFirst = cluster; rStep = nClusters; rEnd = nReads;
     xBase = xbuf + (size_t)cluster * kXStride;

@@ -190,3 +190,27 @@ def test_config4b_hamming74_water64_composite_tier_c(da, oracle_mod, ref_data):
     assert da.symbolsToBytes(out[0]) == payload and da.symbolsToBytes(out[1]) == payload
     assert ll[1] < ll[0]
     dec.close()
+
+
+@pytest.mark.parametrize("mach,fa,flags,members", [("s16h74l4c4.json", "hello.s16h74.del.fa", dict(global_=True), 4),
+                                                   ("s16mr2l4c4.json", "hello.s16mr2.fa", dict(), 3)])
+def test_tier_c_clusters_split_over_xcds(da, oracle_mod, ref_data, mach, fa, flags, members):
+    """cluster_spread=1 puts the members of a cluster into neighbouring blocks, i.e. onto DIFFERENT XCDs (private L2s): the
+    exchange is 8-byte agent-scope atomics and sc1 accesses on both sides, so the placement is a matter of speed only -- the
+    census says the clusters were split, and every cell is still the oracle's."""
+    O = oracle_mod
+    path = os.path.join(ref_data, mach)
+    m = da.Machine.fromFile(path)
+    dec = da.ViterbiDecoder(m, da.MutatorParams.fromFlags(**flags), options="tier=C,cluster=%d,cluster_spread=1" % members)
+    orc = O.ViterbiOracle(O.Machine.from_file(path), O.MutatorParams.from_cli(**flags))
+    reads = [seq for _, seq in da.read_fastseqs(os.path.join(ref_data, fa))] + [m.encodeBytes(bytes([i, 255 - i, 7 * i % 256])) for i in range(11)]
+    out, ll, st = dec.decode(reads)
+    clusters, split = dec.cluster_census()
+    assert clusters == len(reads) and split == clusters, (clusters, split)
+    for i, r in enumerate(reads):
+        s, oll, olat = orc.decode(r, want_lattice=(i == 0))
+        assert out[i] == s and ll[i] == oll
+        if i == 0:
+            lat = np.ascontiguousarray(dec.lattice(i, len(r)).transpose(0, 2, 1))
+            assert np.array_equal(lat.view(np.uint64), olat.view(np.uint64))
+    dec.close()

@@ -18,7 +18,7 @@ def counter(name):
 
 fetch, write = counter("FETCH_SIZE"), counter("WRITE_SIZE")
 bench = json.loads(open(os.path.join(d, "pmc_FETCH_SIZE_bench.json")).read().strip().splitlines()[-1])
-res = {"command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> -- python3 bench.py <args> --steps 1 --warmup 0 --cpu-seconds 0 (one pass per counter; tools/profile_round2.sh)",
+res = {"command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> -- python3 bench.py <args> --steps 1 --warmup 0 --cpu-seconds 0 --timed-only (one pass per counter; tools/profile_round3.sh)",
        "workload": bench["config"]["workload"], "kernel": kernel, "launches": len(fetch),
        "FETCH_SIZE_kb": sum(float(r["Counter_Value"]) for r in fetch), "WRITE_SIZE_kb": sum(float(r["Counter_Value"]) for r in write),
        "scratch_bytes_per_lane": fetch[0]["Scratch_Size"] if fetch else None, "vgprs": fetch[0]["VGPR_Count"] if fetch else None,
