@@ -420,7 +420,7 @@ def main():
         t_all = time.perf_counter()
         for name, fn in (
                 ("configs[1]", lambda: viterbi_line(ctx, 1, "a", 64, 1, 1, 4.0)),
-                ("configs[3] (water64.1*l4c4)", lambda: viterbi_line(ctx, 3, "a", 2085, 1, 1, 4.0)),
+                ("configs[3] (water64.1*l4c4)", lambda: viterbi_line(ctx, 3, "a", 6255, 1, 1, 4.0)),
                 ("configs[3] as written (hamming74*dropdot*water64.1*l4c4)", lambda: viterbi_line(ctx, 3, "b", 16, 1, 0, 4.0)),
                 ("configs[4]", lambda: bench_fwdback.fwdback_line(ctx, 0, 2, 1, 4.0, False))):
             t1 = time.perf_counter()
