@@ -506,10 +506,13 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
                 hipMalloc((void**)&m->dFoldTab, std::max<size_t>(p.foldTab.size(), 1) * 4) != hipSuccess ||
                 hipMemcpy(m->dFoldTab, p.foldTab.data(), p.foldTab.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
               throw std::runtime_error("tier C exchange buffer allocation failed");
-            double seconds = 2.0;   // watchdog per lattice column (a column takes tens of microseconds)
+            // watchdog per lattice column.  A column takes tens of microseconds, but the clock keeps running while the device's
+            // scheduler lets another queue's kernel run (two cluster launches at once on one card were seen to stall each other
+            // for 2-6 s at a time): the limit only has to turn a protocol failure into an error instead of a hung GPU
+            double seconds = 30.0;
             if (const char* s = opt("cluster_timeout_s")) seconds = std::max(0.001, atof(s));
             m->timeoutTicks = (unsigned long long)(seconds * 1e8);   // s_memrealtime counts at 100 MHz
-            double arrive = 60.0;   // ... and for the work-groups of a cluster to have all been started (CUs held by others)
+            double arrive = 120.0;  // ... and for the work-groups of a cluster to have all been started (CUs held by others)
             if (const char* s = opt("cluster_arrive_s")) arrive = std::max(0.001, atof(s));
             m->arriveTicks = (unsigned long long)(arrive * 1e8);
             if (const char* s = opt("cluster_spread")) m->clusterSpread = atoi(s) != 0;

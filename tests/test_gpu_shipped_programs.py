@@ -54,11 +54,11 @@ def test_two_cluster_models_decode_at_once(da, oracle_mod, ref_data):
     m = da.Machine.fromFile(os.path.join(ref_data, "s16h74l4c4.json"))
     params = da.MutatorParams.fromFlags(global_=True)
     rng = random.Random(4)
-    reads = _reads(da, m, rng, [29] * 300, rate=0.01)
+    reads = _reads(da, m, rng, [29] * 200, rate=0.01)
     lone = da.ViterbiDecoder(m, params, options="tier=C,cluster=2")
     want = lone.decode(reads)
     lone.close()
-    decs = [da.ViterbiDecoder(m, params, options="tier=C,cluster=2,arena_fraction=0.3") for _ in range(2)]
+    decs = [da.ViterbiDecoder(m, params, options="tier=C,cluster=2,arena_fraction=0.25") for _ in range(2)]
     got, errs = [None, None], [None, None]
 
     def work(i):
@@ -71,7 +71,7 @@ def test_two_cluster_models_decode_at_once(da, oracle_mod, ref_data):
         t.start()
     for t in threads:
         t.join()
-    assert errs == [None, None], errs
+    assert errs == [None, None], [str(e) for e in errs]
     for g in got:
         assert g[0] == want[0] and np.array_equal(g[1].view(np.uint64), want[1].view(np.uint64)) and np.array_equal(g[2], want[2])
     for d in decs:

@@ -208,9 +208,9 @@ def test_tier_c_clusters_split_over_xcds(da, oracle_mod, ref_data, mach, fa, fla
     clusters, split = dec.cluster_census()
     assert clusters == len(reads) and split == clusters, (clusters, split)
     for i, r in enumerate(reads):
-        s, oll, olat = orc.decode(r, want_lattice=(i == 0))
-        assert out[i] == s and ll[i] == oll
+        res = orc.decode(r, want_lattice=(i == 0))
+        assert out[i] == res[0] and ll[i] == res[1]
         if i == 0:
             lat = np.ascontiguousarray(dec.lattice(i, len(r)).transpose(0, 2, 1))
-            assert np.array_equal(lat.view(np.uint64), olat.view(np.uint64))
+            assert np.array_equal(lat.view(np.uint64), res[2].view(np.uint64))
     dec.close()
