@@ -67,9 +67,12 @@ class Machine:
         return self._encode(_l.lib().dnas_encode_bytes, bytes(payload))
 
     def __del__(self):
-        if getattr(self, "_h", None) is not None and self._h.value:
-            _l.lib().dnas_machine_free(self._h)
-            self._h = ctypes.c_void_p()
+        try:      # (at interpreter shutdown the module globals may be gone already)
+            if getattr(self, "_h", None) is not None and self._h.value:
+                _l.lib().dnas_machine_free(self._h)
+                self._h = ctypes.c_void_p()
+        except Exception:
+            pass
 
 
 class MutatorParams:
@@ -212,9 +215,12 @@ class FlatModel:
         return buf.value.decode()
 
     def __del__(self):
-        if getattr(self, "_h", None) is not None and self._h.value:
-            _l.lib().dnas_flat_free(self._h)
-            self._h = ctypes.c_void_p()
+        try:      # (at interpreter shutdown the module globals may be gone already)
+            if getattr(self, "_h", None) is not None and self._h.value:
+                _l.lib().dnas_flat_free(self._h)
+                self._h = ctypes.c_void_p()
+        except Exception:
+            pass
 
 
 def pack_reads(reads):
@@ -294,7 +300,10 @@ class ViterbiDecoder:
             self._h = ctypes.c_void_p()
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def read_fastseqs(path):
@@ -369,9 +378,12 @@ class StockholmDB:
                     cm_out=arr(v.cm_out, int(co_off[-1]), np.int32), cm_out_off=co_off, n=n)
 
     def __del__(self):
-        if getattr(self, "_h", None) is not None and self._h.value:
-            _l.lib().dnas_pairs_free(self._h)
-            self._h = ctypes.c_void_p()
+        try:      # (at interpreter shutdown the module globals may be gone already)
+            if getattr(self, "_h", None) is not None and self._h.value:
+                _l.lib().dnas_pairs_free(self._h)
+                self._h = ctypes.c_void_p()
+        except Exception:
+            pass
 
 
 def _pair_ptrs(pk):
@@ -412,7 +424,10 @@ class ForwardBackward:
             self._h = ctypes.c_void_p()
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def expectedCounts(params, pairs, strict=False, device=0):

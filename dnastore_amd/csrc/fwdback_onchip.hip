@@ -1,29 +1,26 @@
-// Forward-backward E-step of the mutator pair-HMM, ON CHIP: the banded Forward and Backward matrices of a pair
-// (reference src/fwdback.cpp:43-116) and its posterior counts (fwdback.cpp:154-188, fwdback.h:92-112) never become
-// whole anywhere.  HBM sees the two sequences, the guide columns, 21+P counts + one log-likelihood per pair, and a
-// small per-slot scratch area that stays in L2 / Infinity Cache (checkpoint rows, the duplication lanes of one block).
+// Forward-backward E-step of the mutator pair-HMM as a wavefront per alignment pair: the banded Forward and Backward
+// matrices (reference src/fwdback.cpp:43-116) and the posterior counts (fwdback.cpp:154-188, fwdback.h:92-112).
+// (The file keeps its round-2 name: the first version held a block of the matrices in LDS.)
 //
 // W lanes work on one pair as a systolic wavefront (W = 16 or 32: the widest envelope row the kernel serves).  Lane l owns
-// the rows ip = W*b + l of the current block b of W rows; at step a it computes the cell (ip, a - ip) if that lies in the
-// row's envelope [lo(ip), hi(ip)].  A cell needs (ip-1, op-1) and (ip-1, op) -- what the lane below it computed two steps
-// and one step ago: they come over by a lane shuffle, not through memory -- and (ip, op-1), its own previous step, kept
-// in registers.  A row is at most W cells wide, so a lane has left its row before the next block hands it another one.
+// the rows ip = l, l + W, l + 2W ...; at step a it computes the cell (ip, a - ip) if that lies in the row's envelope
+// [lo(ip), hi(ip)].  A cell needs (ip-1, op-1) and (ip-1, op) -- what the lane below it computed two steps and one step ago:
+// they come over by a lane shuffle, not through memory -- and (ip, op-1), its own previous step, kept in registers.  A row
+// is at most W cells wide, so a lane has left its row before its next one comes up.
 //
-//   pass 1   Forward over all rows; only the S and D lanes of the last row of every block are kept (a "checkpoint",
-//            2 * W doubles per block, in the slot's scratch): a row is a function of the S and D lanes of the row above
-//            it, because the duplication lanes T only run along a row (fwdback.cpp:57-60).
-//   pass 2   blocks from the last to the first: the block's Forward rows are recomputed from the checkpoint above it and go,
-//            whole (S, D and the duplication lanes of W x W cells), to the slot's scratch; then the Backward wavefront runs up
-//            the block -- the row below comes over by shuffle, the block below left its first row in LDS; the Forward cells a
-//            Backward cell needs (its own, the one to its left, two of the row above) are loaded at the top of its step, long
-//            before the counts use them -- and every finished Backward cell adds its seven posterior terms (fwdback.h:92-112)
-//            to the pair's counts.
+//   pass 1   Forward over all rows; every finished cell (S, D and the P duplication lanes) goes to the slot's scratch in HBM
+//            (330 KB for a 256-nt pair: bandwidth this chip has to spare -- 0.8 TB/s at 1.4 * 10^6 pairs/s -- bought for not
+//            evaluating any Forward cell twice; the round-3 version before this one recomputed blocks of W rows from
+//            checkpoints and was 1.5 x slower).
+//   pass 2   Backward, one continuous wavefront up the rows: the row below comes over by shuffle from the lane above; the
+//            Forward cells a Backward cell needs (its own, the duplication lanes of the one to its left, two of the row above)
+//            are loaded at the top of its step, long before the counts use them; every finished Backward cell adds its seven
+//            posterior terms (fwdback.h:92-112) to the pair's counts.
 //
-// LDS per pair: 2 KB at W = 16 (envelope bounds, two boundary rows, the substitution counts; round 2 kept the Forward block
-// and the checkpoints there: 26 KB), so what a CU holds is bounded by registers (128 per lane): 16 waves = 64 pairs instead of
-// 6 pairs on 3 half-filled waves.  A work-group is ONE wave (64 / W pairs) and walks the list of pairs with a stride of the
-// grid; nothing in it needs a work-group barrier.  The kernel waits on memory (the table look-ups of the log-sum-exps come from
-// L2, the Forward cells from L2 / Infinity Cache): pairs per second grew in step with the waves per CU (4.0, 4.9 * 10^5 at 5, 6).
+// LDS per pair: the envelope bounds (4 B per input position) and the substitution counts, so what a CU holds is bounded by
+// registers: 168 per lane without spills = 12 waves = 48 pairs per CU (round 2: 6 pairs on 3 half-filled waves, 26 KB of LDS
+// each).  A work-group is ONE wave (64 / W pairs) and walks the list of pairs with a stride of the grid; nothing in it needs a
+// work-group barrier.
 //
 // The arithmetic of a cell is the reference's, operation for operation (lse() with the reference's 100 001-entry
 // table, uploaded once per handle and L2 resident; the two divisions by the table step are formed with a reciprocal and one
@@ -31,9 +28,9 @@
 // per-pair log-likelihoods are bit-identical to the CPU oracle's.  Counts are sums of exp() terms added in another order
 // (per lane, then over the lanes in a fixed tree), so they agree to ~1e-12 relative and are reproducible run to run.
 //
-// What bounds it: the instruction stream of a cell (9 table-interpolated log-sum-exps forward, the same plus 17 fp64 exp
-// backward) -- fp64 vector issue, not bytes: bench.py --config 4 reports the share of the chip's fp64 issue slots the
-// kernel's instructions take.
+// What bounds it: the instruction stream of a cell (9 table-interpolated log-sum-exps forward, the same plus 16 fp64 exp
+// backward) -- fp64 vector issue, not bytes: bench.py --config 4 reports the share of the chip's vector issue slots the
+// kernel's instructions take (roofline.issue).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
