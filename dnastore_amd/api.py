@@ -170,7 +170,8 @@ class FlatModel:
 
     def cluster_plan(self, members=0):
         """Tier-C tables (members = 1: the tier-A plan): dict(G, K, T, n_entries, n_s_rows, n_inbox_rows, shapes int32[K][6],
-        entries uint32[G][n_entries][T], meta uint32[G][K][T], member_of, lds_index, lattice_slot, fold uint32[G][n_inbox_rows][T])."""
+        entries uint32[G][n_entries][T], meta uint32[G][K][T], member_of, lds_index, lattice_slot, fold uint32[G][n_inbox_rows][T],
+        proxy_member, proxy_lds_index: the places of the plan's proxies)."""
         n = self.view.contents.n_states
         info = np.zeros(8, dtype=np.int32)
         _l.check(_l.lib().dnas_tierc_plan(self.view, int(members), info.ctypes.data, None, None, 0, None, None, None, None, None))
@@ -184,8 +185,14 @@ class FlatModel:
         lat = np.full(n, -1, dtype=np.int32)
         _l.check(_l.lib().dnas_tierc_plan(self.view, G, info.ctypes.data, shapes.ctypes.data, ent.ctypes.data, ent.size, meta.ctypes.data,
                                           member_of.ctypes.data, lds.ctypes.data, lat.ctypes.data, fold.ctypes.data))
+        n_prox = int(info[6])
+        pm = np.zeros(max(n_prox, 1), dtype=np.int32)
+        pl = np.zeros(max(n_prox, 1), dtype=np.int32)
+        if n_prox:
+            _l.check(_l.lib().dnas_tierc_plan_proxies(self.view, G, pm.ctypes.data, pl.ctypes.data, n_prox))
         out = dict(G=G, K=K, T=T, n_entries=ne, n_s_rows=int(info[4]), n_inbox_rows=int(info[5]), shapes=shapes, entries=ent, meta=meta,
-                   member_of=member_of, lds_index=lds, lattice_slot=lat, fold=fold[:, :int(info[5])])
+                   member_of=member_of, lds_index=lds, lattice_slot=lat, fold=fold[:, :int(info[5])],
+                   proxy_member=pm[:n_prox], proxy_lds_index=pl[:n_prox])
         return out
 
     def tune_record_name(self, members=1, threads=0):

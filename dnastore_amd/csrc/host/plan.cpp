@@ -152,11 +152,12 @@ std::vector<int> placeLanes(int N, int G, int K, int T, const std::vector<Edge>&
 
 TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const PlanChoice& choice = PlanChoice()) {
   TierAPlan p;
-  const int N = fm.n_states, D = fm.max_dup_len;
+  const int N0 = fm.n_states, D = fm.max_dup_len;   // N0: the machine's states
+  int N = N0;                                       // ... plus the proxies of a cluster (below)
   if (T != 1024 && T != 512) { TierAPlan bad; bad.whyNot = "work-groups of 512 or 1024 threads"; return bad; }
   // a work-group fills a CU either way: 16 waves of 128 registers, or 8 waves of 256 with twice the rows per thread
   const int maxRows = kTierAMaxRows * 1024 / T, maxEntries = kMaxEntries * 1024 / T;
-  p.N = N; p.D = D; p.T = T; p.G = G;
+  p.N = N0; p.D = D; p.T = T; p.G = G;
   auto no = [&](const std::string& why) { p.ok = false; p.whyNot = why; return p; };
   if (D > 8) return no("more than 8 duplication lanes");
   if (G < 1 || G > kTierCMaxMembers) return no("cluster size out of range");
@@ -205,20 +206,52 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const P
   // member folds into the state's LDS accumulators, slot r*T + t by thread t.
   std::vector<int> part(N, 0);
   if (G > 1) part = partitionStates(N, edges, walk, G, (int)((long)K * T * 93 / 100));
-  // The slots of the states that another member reaches over a NULL edge come first: only they need an S cell in
-  // the inbox (null edges carry S as well as D, viterbi.cpp:137-151), and the kernel polls S cells for those rows only.
-  std::vector<int> inboxSlot(N, -1);
+  // PROXIES.  A state that many states of ANOTHER member reach over null edges (the 258 538-state composite's state 0:
+  // 2 245 null edges from the 20 other members) would need a cell per edge.  Instead those edges end at a proxy INSIDE the
+  // source member -- an extra "state" without emission or context, fed over the same null edges with the same scores --
+  // whose one out-edge, a null edge of score class 0 (nothing is added), carries the maximum to the real destination: the
+  // sources combine in LDS and one thread talks to the other member.  max is associative and the proxy adds nothing, so the
+  // destination's D and S cells receive exactly max over the sources of (D + score) and (S + score) as before; what the
+  // proxy adds of its own (S >= D + delEnd, like every state) the destination derives from its D cell anyway.
+  if (G > 1 && !getenv("DNAS_PLAN_NO_PROXIES")) {
+    int kProxyMin = 3;     // edges of one member into one state from which a proxy pays (a place, and a row's delay)
+    if (const char* e = getenv("DNAS_PLAN_PROXY_MIN")) kProxyMin = std::max(2, atoi(e));   // tests
+    std::map<std::pair<int, int>, std::vector<int>> byPair;   // (source member, destination) -> the null edges between them
+    for (size_t ei = 0; ei < edges.size(); ++ei) {
+      const Edge& e = edges[ei];
+      if (e.isNull && part[e.src] != part[e.dst]) byPair[{part[e.src], e.dst}].push_back((int)ei);
+    }
+    for (const auto& kv : byPair) {
+      if ((int)kv.second.size() < kProxyMin) continue;
+      const int P = N++;
+      part.push_back(kv.first.first);
+      parent.push_back(edges[(size_t)kv.second.front()].src);
+      walk.push_back(P);
+      for (int ei : kv.second) edges[(size_t)ei].dst = P;
+      edges.push_back(Edge{P, kv.first.second, 0, 0, 1});
+    }
+    if (N > N0) {
+      outOf.assign(N, {}); inOf.assign(N, {});
+      for (size_t e = 0; e < edges.size(); ++e) { outOf[edges[e].src].push_back((int)e); inOf[edges[e].dst].push_back((int)e); }
+    }
+  }
+  // Every edge between two members gets a cell of its own in the destination member's inbox (a MAILBOX: one writer, the
+  // thread that owns the edge's source state; one reader, the thread of the owner that folds it), so that an offer is a
+  // plain 8-byte store of a value that only grows within a column -- no atomic, and on a cluster that sits on one XCD the
+  // cell never leaves that XCD's L2.  The cells of NULL edges come first: only they need an S cell as well (null edges carry
+  // S as well as D, viterbi.cpp:137-151), and the kernel polls S cells for those rows only.
+  std::vector<int> inboxSlot(edges.size(), -1);
   std::vector<int> inboxCount(G, 0), inboxSCount(G, 0);
-  std::vector<char> remoteNull(N, 0);
   long nCross = 0;
-  for (const Edge& e : edges)
-    if (part[e.src] != part[e.dst]) { ++nCross; if (e.isNull) remoteNull[e.dst] = 1; }
   for (int pass = 0; pass < 2; ++pass)
-    for (const Edge& e : edges)
-      if (part[e.src] != part[e.dst] && inboxSlot[e.dst] < 0 && (pass == 1 || remoteNull[e.dst])) {
-        inboxSlot[e.dst] = inboxCount[part[e.dst]]++;
+    for (size_t ei = 0; ei < edges.size(); ++ei) {
+      const Edge& e = edges[ei];
+      if (part[e.src] != part[e.dst] && (pass == 0) == (e.isNull != 0)) {
+        ++nCross;
+        inboxSlot[ei] = inboxCount[part[e.dst]]++;
         if (pass == 0) ++inboxSCount[part[e.dst]];
       }
+    }
   p.crossEdges = edges.empty() ? 0. : (double)nCross / (double)edges.size();
   for (int j = 0; j < N; ++j)
     if (parent[j] >= 0 && part[parent[j]] != part[j]) parent[j] = -1;   // the dealing follows a member's own subtrees
@@ -336,12 +369,13 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const P
   int nInboxRows = 0;
   for (int g = 0; g < G; ++g) nInboxRows = std::max(nInboxRows, (inboxCount[g] + T - 1) / T);
   if (G > 1 && nInboxRows == 0) nInboxRows = 1;   // (a cluster whose members never talk: keep the kernel's shape)
+  nInboxRows = (nInboxRows + 1) & ~1;             // the kernel loads the rows in pairs (cell (r, t) at (r/2)*2T + 2t + (r&1), 16 bytes per thread)
   int nInboxSRows = 0;
   for (int g = 0; g < G; ++g) nInboxSRows = std::max(nInboxSRows, (inboxSCount[g] + T - 1) / T);
   p.nGRows = nInboxRows;
   p.nGSRows = nInboxSRows;
   if ((long)G * nInboxRows * T > (1l << 20)) return no("more than 2^20 exchange cells");
-  if (nInboxRows > 7) return no("more than " + std::to_string(7 * T) + " states of a member are fed by other members");
+  if (nInboxRows > 12) return no("more than " + std::to_string(12 * T) + " edges from other members into one member");
 
   std::vector<Type> type(N);
   int maxOut = 0;
@@ -380,7 +414,7 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const P
   if (!reserveRows) nRemoteRows = nRemoteSRows = 0;
   if (getenv("DNAS_PLAN_DEBUG") && G > 1) {
     for (int g = 0; g < G; ++g)
-      fprintf(stderr, "plan member %d: %zu states, %d fed by other members, %d with null in-edges\n", g, walkOf[g].size(), inboxCount[g], nNullDestOf[g]);
+      fprintf(stderr, "plan member %d: %zu states, %d edges from other members, %d states with null in-edges\n", g, walkOf[g].size(), inboxCount[g], nNullDestOf[g]);
     fprintf(stderr, "plan: K %d inbox rows %d cross edges %.4f\n", K, nInboxRows, p.crossEdges);
   }
 
@@ -738,14 +772,16 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const P
 
   // index spaces: a member's LDS index row*T + lane (consecutive lanes -> consecutive bank pairs), and
   // the lattice slot member*K*T + (row/2)*2T + 2*lane + (row&1) used in HBM and by the traceback
-  p.memberOf.assign(part.begin(), part.end());
+  p.memberOf.assign(part.begin(), part.begin() + N0);
   p.slotOf.assign(N, -1);
   p.stateOf.assign((size_t)p.NS, -1);       // by (member*K + row)*T + lane
   for (int j = 0; j < N; ++j) {
     const int row = rowOfState[j], lane = laneOf[j];
-    p.stateOf[((size_t)part[j] * K + row) * T + lane] = j;
+    if (j < N0) p.stateOf[((size_t)part[j] * K + row) * T + lane] = j;      // (a proxy's place holds no state of the machine)
+    else { p.proxyMember.push_back(part[j]); p.proxyLds.push_back(row * T + lane); }
     p.slotOf[j] = part[j] * p.NSm + (row >> 1) * 2 * T + 2 * lane + (row & 1);
   }
+  p.slotOf.resize(N0);
 
   // entries, one per out-edge (layout: viterbi_tiera.hip).  0: no edge.
   const unsigned dcBase = (unsigned)p.nSRows * T * 8 + 64;     // byte address of DC[0]: behind the S stripes and a pad
@@ -760,7 +796,8 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const P
       unsigned ent;
       if (part[e.dst] != part[j]) {
         // inbox cell of the destination:  [0:2) class | bit 2 | [3:23) cell | bit 23 null edge | [24:26) emitted base
-        const unsigned cell = (unsigned)(part[e.dst] * nInboxRows * T + inboxSlot[e.dst]);
+        const int slot = inboxSlot[entOut[j][i]], sr = slot / T, st = slot % T;
+        const unsigned cell = (unsigned)(part[e.dst] * nInboxRows * T + (sr >> 1) * 2 * T + 2 * st + (sr & 1));
         if (e.isNull && p.rows[drow].sIdx < 0) return no("internal: null edge into a row without S cells");
         ent = (unsigned)e.sc | 4u | (cell << 3) | (e.isNull ? 1u << 23 : (unsigned)(e.base & 3) << 24);
       } else {
@@ -781,13 +818,14 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const P
   // fold table: inbox slot r*T + t of a member -> LDS cells of the state behind it: DC byte address >> 3 | SC byte
   // address >> 3 << 16 (0xffff: the state has no S cell); 0: slot unused
   p.foldTab.assign((size_t)G * nInboxRows * T, 0u);
-  for (int j = 0; j < N; ++j)
-    if (inboxSlot[j] >= 0) {
-      const int row = rowOfState[j], lane = laneOf[j];
+  for (size_t ei = 0; ei < edges.size(); ++ei)
+    if (inboxSlot[ei] >= 0) {
+      const Edge& e = edges[ei];
+      const int j = e.dst, row = rowOfState[j], lane = laneOf[j];
       const unsigned dc = (dcBase + (unsigned)(row * T + lane) * 8u) >> 3;
-      if (remoteNull[j] && (p.rows[row].sIdx < 0 || inboxSlot[j] >= nInboxSRows * T)) return no("internal: inbox S cell");
-      const unsigned scc = remoteNull[j] ? (unsigned)(p.rows[row].sIdx * T + lane) : 0xffffu;
-      p.foldTab[(size_t)part[j] * nInboxRows * T + (size_t)inboxSlot[j]] = dc | (scc << 16);
+      if (e.isNull && (p.rows[row].sIdx < 0 || inboxSlot[ei] >= nInboxSRows * T)) return no("internal: inbox S cell");
+      const unsigned scc = e.isNull ? (unsigned)(p.rows[row].sIdx * T + lane) : 0xffffu;
+      p.foldTab[(size_t)part[j] * nInboxRows * T + (size_t)inboxSlot[ei]] = dc | (scc << 16);
     }
 
   // meta: mdl | ctx << 4 | bit29 real state | bit30 reference's last state | bit31 reference's state 0
@@ -799,7 +837,7 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const P
       meta = fm.mdl[j] & 15u;
       for (int q = 0; q < fm.mdl[j] && q < 8; ++q) meta |= (unsigned)(fm.ctx[(size_t)j * D + q] & 3u) << (4 + 2 * q);
       if (j == 0) meta |= 0x80000000u;
-      if (j == N - 1) meta |= 0x40000000u;
+      if (j == N0 - 1) meta |= 0x40000000u;
       meta |= 0x20000000u;   // slot holds a real state
     }
     p.metaTab[idx] = meta;

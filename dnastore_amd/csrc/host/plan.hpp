@@ -8,10 +8,10 @@
 //  * every state owns an LDS accumulator DC[row*T + thread] that its in-edges are pushed into
 //    (ds_max_f64), and -- if it has null in-edges -- a second one, SC, in a stripe of T cells
 //    that its row shares ("S rows")
-//  * in a cluster, a state with an in-edge from ANOTHER member also owns a slot of its member's inbox:
-//    cells of the cluster's exchange buffer in global memory that the other members offer into
-//    (global_atomic_max_f64 at agent scope) and that the member folds into the state's LDS cells, slot
-//    r*T + t by thread t, once per sweep
+//  * in a cluster, an EDGE into another member owns a cell of that member's inbox: a cell of the cluster's
+//    exchange buffer in global memory with one writer (the thread that holds the edge's source: an 8-byte
+//    store of a value that only grows within a column) and one reader (the member folds cell r*T + t into the
+//    destination state's LDS cells by thread t, once per sweep)
 //  * a state's OUT-edges become per-thread 32-bit entries (kept in registers by the kernel):
 //      emit edge  D(dst) >= max(D+delExtend, S+delOpen) + score        (viterbi.cpp:123-125)
 //                 and, between columns, S(dst) >= S + score + noGap + sub   (viterbi.cpp:92-95)
@@ -39,7 +39,7 @@ struct TierAPlan {
   std::string whyNot;
   int T = 1024, K = 0, D = 0, N = 0, nSRows = 0, nClasses = 1, nEntries = 0;
   int G = 1;                      // work-groups per read (1: tier A)
-  int nGRows = 0;                 // inbox rows: a member's inbox holds nGRows * T slots (0 when G == 1)
+  int nGRows = 0;                 // inbox rows: a member's inbox holds nGRows * T cells (0 when G == 1)
   int nGSRows = 0;                // ... of which the first nGSRows * T also carry an S cell (states reached over a null edge)
   int NSm = 0;                    // lattice slots per member (= K*T)
   int NS = 0;                     // lattice slots per column (= G*K*T)
@@ -51,6 +51,7 @@ struct TierAPlan {
   std::vector<int32_t> stateOf;   // [G*K*T] index (member*K + row)*T + thread -> state or -1
   std::vector<uint32_t> entTab;   // [G][nEntries][T]  out-edges, see viterbi_tiera.hip
   std::vector<uint32_t> metaTab;  // [G][K][T]  mdl | ctx<<4 | flags
+  std::vector<int32_t> proxyMember, proxyLds;   // cluster proxies (plan.cpp): member and row*T + lane of each
   std::vector<uint32_t> foldTab;  // [G][nGRows][T]  inbox slot -> LDS cells of its state (DC addr >> 3 | SC addr >> 3 << 16), 0: unused
   double score[4] = {0, 0, 0, 0};
   size_t ldsBytes = 0;
@@ -60,9 +61,10 @@ struct TierAPlan {
   double sameWave = 0;            // share of forward edges whose ends sit in the same wave
   double crossEdges = 0;          // share of edges that go through the exchange buffer
   long exchangeCells() const { return (long)G * nGRows * T; }   // cells of one exchange array
+  long exchangeStride() const { return 3 * exchangeCells() + 2 * ((G + 15) & ~15); }   // doubles per cluster: XA.dc | XB.dc | XB.sc | reduction cells (viterbi_tiera.hip kXStride)
 };
 
-constexpr int kPlanVersion = 4;      // bumped when the planner changes what it produces: recorded tuning verdicts name it
+constexpr int kPlanVersion = 5;      // bumped when the planner changes what it produces: recorded tuning verdicts name it
 
 // What the caller (a tuning record, an option, an experiment) decides about the row program; -1: as the environment says
 // (DNAS_PLAN_ORDER, DNAS_PLAN_SLACK), else the default.

@@ -500,7 +500,7 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
             const int xcds = std::max(1, cus / 32);
             m->maxClusters = std::max(1, xcds * ((cus / xcds) / p.G));      // one work-group per CU, whole clusters per XCD
             if (const char* s = opt("max_clusters")) m->maxClusters = std::max(1, atoi(s));
-            m->xStride = 3 * (size_t)p.exchangeCells() + 8;
+            m->xStride = (size_t)p.exchangeStride();
             if (hipMalloc((void**)&m->dXbuf, m->xStride * (size_t)m->maxClusters * sizeof(double)) != hipSuccess ||
                 hipMalloc((void**)&m->dSync, (size_t)m->maxClusters * 64 * sizeof(unsigned)) != hipSuccess ||
                 hipMalloc((void**)&m->dFoldTab, std::max<size_t>(p.foldTab.size(), 1) * 4) != hipSuccess ||
@@ -1228,7 +1228,7 @@ extern "C" int dnas_tierc_precompile(const dnas_flat_model* fm, int32_t members,
 }
 
 // Analysis / test aid: the tier-C tables of a machine exactly as the kernel receives them (no GPU needed).
-// info[8] = {G, K, T, entries per member, S stripes, exchange rows, 0, 0}; every other output may be NULL:
+// info[8] = {G, K, T, entries per member, S stripes, exchange rows, proxies, 0}; every other output may be NULL:
 // row_shapes[K][6], entries[G][n_entries][T], meta[G][K][T], member_of[N], lds_index[N] = row*T + lane inside
 // the member, lattice_slot[N], fold[G][inbox rows][T].
 extern "C" int dnas_tierc_plan(const dnas_flat_model* fm, int32_t members, int32_t* info, int32_t* row_shapes, uint32_t* entries,
@@ -1238,7 +1238,7 @@ extern "C" int dnas_tierc_plan(const dnas_flat_model* fm, int32_t members, int32
   try {
     const dnas::TierAPlan p = members == 1 ? dnas::buildTierAPlan(*fm) : dnas::chooseClusterPlan(*fm, members, 0);
     if (!p.ok) return dnas::fail(DNAS_E_UNSUPPORTED, p.whyNot);
-    info[0] = p.G; info[1] = p.K; info[2] = p.T; info[3] = p.nEntries; info[4] = p.nSRows; info[5] = p.nGRows; info[6] = info[7] = 0;
+    info[0] = p.G; info[1] = p.K; info[2] = p.T; info[3] = p.nEntries; info[4] = p.nSRows; info[5] = p.nGRows; info[6] = (int32_t)p.proxyMember.size(); info[7] = 0;
     if (row_shapes)
       for (int k = 0; k < p.K; ++k) {
         const dnas::RowShape& r = p.rows[k];
@@ -1262,7 +1262,24 @@ extern "C" int dnas_tierc_plan(const dnas_flat_model* fm, int32_t members, int32
   }
 }
 
-// Tier C diagnostics of the last call: clusters that ran, and how many of them had members on more than one XCD.
+// ... and the places of its proxies (plan.cpp: extra places that combine a member's null edges into one state of another
+// member): member and row*T + lane of each, info[6] of them.
+extern "C" int dnas_tierc_plan_proxies(const dnas_flat_model* fm, int32_t members, int32_t* proxy_member, int32_t* proxy_lds_index, size_t cap) {
+  if (!fm || !proxy_member || !proxy_lds_index) return dnas::fail(DNAS_E_INVALID, "null argument");
+  try {
+    const dnas::TierAPlan p = members == 1 ? dnas::buildTierAPlan(*fm) : dnas::chooseClusterPlan(*fm, members, 0);
+    if (!p.ok) return dnas::fail(DNAS_E_UNSUPPORTED, p.whyNot);
+    if (cap < p.proxyMember.size()) return dnas::fail(DNAS_E_INVALID, "proxy buffer too small");
+    if (!p.proxyMember.empty()) {
+      memcpy(proxy_member, p.proxyMember.data(), p.proxyMember.size() * sizeof(int32_t));
+      memcpy(proxy_lds_index, p.proxyLds.data(), p.proxyLds.size() * sizeof(int32_t));
+    }
+    return DNAS_OK;
+  } catch (const std::exception& e) {
+    return dnas::fail(DNAS_E_DEVICE, e.what());
+  }
+}
+
 // The name of the tuning record of a tier-A machine (tune_row_program above; tools/make_tune_records.py writes the records
 // that ship with the library from bench-like reads).
 extern "C" int dnas_tune_record_name(const dnas_flat_model* fm, int32_t members, int32_t threads, char* out, size_t cap) {

@@ -23,14 +23,16 @@
 //
 // Machines beyond one CU ("tier C", DNAS_G > 1): a CLUSTER of DNAS_G work-groups shares a read; member g
 // owns a part of the states (host/plan.cpp cuts the machine along its depth-first walk).  Edges inside a
-// member work as above.  A state with an in-edge from another member also owns a slot of its member's
-// INBOX in the cluster's exchange buffer in global memory: the other members offer into it with
-// an agent-scope atomic max, and thread t of the owner folds slot r*T + t into the state's LDS accumulators
-// once per sweep (sc1 loads issued behind the last row of a sweep, ds_max in front of the first row of the next),
-// so the protocol is correct wherever the work-groups run; the launcher places a cluster on one XCD (blockIdx
-// b and b+8 share one) for speed only.  Termination is agreed in two levels: inside a work-group as before,
-// across the cluster through a device-scope epoch GE (bumped after every batch of exchange offers has
-// completed) and one idle word per member.
+// member work as above.  An EDGE into another member owns a cell of that member's INBOX in the cluster's
+// exchange buffer in global memory -- a mailbox: the thread that holds the edge's source state is its only
+// writer and stores what it offers (the value only grows within a column: no atomic), and thread t of the owner
+// folds cell r*T + t into the destination state's LDS accumulators once per sweep (sc1 loads issued behind the
+// last row of a sweep, ds_max in front of the first row of the next).  The launcher places a cluster on one XCD
+// (blockIdx b and b+8 share one); the members compare their XCC ids at the first barrier: on one XCD the
+// stores are plain -- the cells live in that XCD's L2 and never travel to memory --, a split cluster stores
+// write-through (sc1), so the protocol is correct wherever the work-groups run.  Termination is agreed in two
+// levels: inside a work-group as before, across the cluster through a device-scope epoch GE (bumped after
+// every batch of exchange offers has completed) and one idle word per member.
 //
 // Global memory -- tables, lattice columns, exchange buffer -- is addressed the buffer way (descriptor in scalar
 // registers + 32-bit lane offset): no specialisation of this file keeps a pointer in vector registers or spills.
@@ -158,27 +160,16 @@ constexpr int kAuxNt = 2, kAuxSc1 = 16;   // cache policy bits of a buffer acces
 __device__ __forceinline__ unsigned bufLoadU32(rsrc_t r, unsigned laneOff, unsigned uniOff) {
   return __builtin_amdgcn_raw_buffer_load_b32(r, (int)laneOff, (int)uniOff, 0);
 }
-// exchange buffer: 8-byte agent-scope accesses on both sides (the offers are atomics performed at the memory side, the
-// owner's loads and clears carry sc1 and bypass this CU's L1), so a hand-over needs no fence
-// (the atomic is written out: not every hiprtc this library meets knows the builtin of its buffer form; desc = the four
-//  words of the buffer's descriptor)
-__device__ __forceinline__ u32x4 makeDesc(const void* base) {
-  const unsigned long long b = reinterpret_cast<unsigned long long>(base);
-  u32x4 d;
-  d.x = (unsigned)b; d.y = (unsigned)(b >> 32); d.z = 0xffffffffu; d.w = 0x00020000u;
-  return d;
-}
-// The compiler does not look into the statement: the wait states a VMEM instruction needs behind a VALU write of a scalar
-// register it reads (v_readlane restores a spilled descriptor right in front of it: five) are spent by the s_nop, and the
-// uniform part of the offset travels in the vector offset, so that the descriptor is the only scalar operand.
-__device__ __forceinline__ void xMax(u32x4 desc, unsigned laneOff, unsigned uniOff, double v) {
-  asm volatile("s_nop 4\n\tbuffer_atomic_max_f64 %0, %1, %2, 0 offen" : : "v"(v), "v"(laneOff + uniOff), "s"(desc) : "memory");
-}
+// exchange buffer: every cell has ONE writer at a time (the edge's source thread during a column, the owner when it clears
+// the cell between columns; the cluster's barriers order the two) and is read with sc1 loads, which bypass this CU's L1 and
+// are served by the L2.  onXcd (uniform): the whole cluster shares one L2, the stores are plain and stay there; otherwise
+// they are written through to memory (sc1), where the reader's sc1 load finds them.  Either way a hand-over needs no fence.
 __device__ __forceinline__ double xLoad(rsrc_t r, unsigned laneOff, unsigned uniOff) {
   return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)laneOff, (int)uniOff, kAuxSc1));
 }
-__device__ __forceinline__ void xStore(rsrc_t r, unsigned laneOff, unsigned uniOff, double v) {
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)laneOff, (int)uniOff, kAuxSc1);
+__device__ __forceinline__ void xStore(rsrc_t r, bool onXcd, unsigned laneOff, unsigned uniOff, double v) {
+  if (onXcd) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)laneOff, (int)uniOff, 0);
+  else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)laneOff, (int)uniOff, kAuxSc1);
 }
 __device__ __forceinline__ unsigned wLoad(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -205,15 +196,15 @@ constexpr double kFresh = __builtin_huge_val();   // "not evaluated in this colu
 #define DNAS_NT_D 1
 #endif
 // Cluster constants.  Exchange buffer of one cluster: XA.dc | XB.dc | XB.sc, kCells doubles each, cell
-// (member * GROWS + r) * T + t = inbox slot r*T + t of that member (XA: the emit offers between columns,
+// (member * GROWS + r) * T + t = inbox cell r*T + t of that member (XA: the emit offers between columns,
 // XB: the offers of the in-column fixpoint -- two sets, because a fast member is already offering into the
-// fixpoint while a slow one still folds its between-column cells), then the two cells of the end-of-read
-// reduction.  Sync block of one cluster (64 u32): [0] GE, [1] abort,
+// fixpoint while a slow one still folds its between-column cells), then two sets of G cells for the end-of-read
+// reduction (one per member, by read parity).  Sync block of one cluster (64 u32): [0] GE, [1] abort,
 // [2, 2+G) idle word per member, [40] placement census (OR of 1 << XCC id).
 constexpr int G_ = DNAS_G;
 constexpr bool kEarlyOffers = DNAS_G == 1;   // one work-group per read: a column's emit offers are made inside phase C of the column before
 constexpr unsigned kCells = (unsigned)DNAS_G * DNAS_GROWS * DNAS_T;
-constexpr unsigned kXStride = 3u * kCells + 8u;   // doubles per cluster
+constexpr unsigned kXStride = 3u * kCells + 2u * ((unsigned)DNAS_G + 15u & ~15u);   // doubles per cluster (kCells is a multiple of 64: every array starts a 128-byte line)
 
 extern "C" __global__ void __launch_bounds__(DNAS_T)
 viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kEntries][T]
@@ -268,15 +259,31 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
     }
   }
   constexpr unsigned kXA = 0u, kXBd = kCells * 8u, kXBs = 2u * kCells * 8u, kXRed = 3u * kCells * 8u;
-  const u32x4 xBd = makeDesc(xBase);
   const rsrc_t xB = makeRsrc(xBase), rEnt = makeRsrc(entTab), rMeta = makeRsrc(metaTab), rFold = makeRsrc(foldTab);
   const unsigned tid4 = (unsigned)tid * 4u, tid8 = (unsigned)tid * 8u, tid16 = (unsigned)tid * 16u;
-  // own inbox cells: slot r*T + tid of this member -- array base + X_OWN_U(r) uniform, tid8 per lane
-#define X_OWN_U(r) ((unsigned)(((unsigned)member * DNAS_GROWS + (unsigned)(r)) * T) * 8u)
+  // own inbox cells: rows 2m, 2m+1 of a thread are neighbours (cell (r, t) of a member sits at (r/2)*2T + 2t + (r&1), the lattice's
+  // layout), so a pair of rows is one 16-byte load -- array base + X_PAIR_U(m) uniform, tid16 per lane
+  static_assert(DNAS_GROWS % 2 == 0, "inbox rows come in pairs");
+  bool onXcd = false;      // the cluster's members share an XCD (known after the first barrier; no exchange store precedes it)
+#define X_PAIR_U(m2) ((unsigned)(((unsigned)member * DNAS_GROWS + 2u * (unsigned)(m2)) * T) * 8u)
+  auto xLoad2 = [&](unsigned arrayOff, auto mc, double& lo, double& hi) {
+    const dbl2 v2 = __builtin_bit_cast(dbl2, __builtin_amdgcn_raw_buffer_load_b128(xB, (int)tid16, (int)(arrayOff + X_PAIR_U(mc.value)), kAuxSc1));
+    lo = v2.x; hi = v2.y;
+  };
+  auto xClear2 = [&](unsigned arrayOff, auto mc) {
+    dbl2 v2;
+    v2.x = kNegInf; v2.y = kNegInf;
+    if (onXcd) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v2), xB, (int)tid16, (int)(arrayOff + X_PAIR_U(mc.value)), 0);
+    else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v2), xB, (int)tid16, (int)(arrayOff + X_PAIR_U(mc.value)), kAuxSc1);
+  };
   // where slot r*T + tid folds into: byte addresses of the state's DC and SC cells (0 / 0x7fff8: none)
   constexpr int R_ = DNAS_GROWS > 0 ? DNAS_GROWS : 1;
   unsigned FT[R_];
-  if constexpr (G_ > 1) static_for<0, DNAS_GROWS>([&](auto rc) { FT[rc.value] = bufLoadU32(rFold, tid4, (unsigned)rc.value * T * 4u); });
+  unsigned pairUsed = 0;   // bit m: some cell of inbox rows 2m, 2m+1 of this WAVE has a writer (uniform; the other pairs are never loaded)
+  if constexpr (G_ > 1) {
+    static_for<0, DNAS_GROWS>([&](auto rc) { FT[rc.value] = bufLoadU32(rFold, tid4, (unsigned)rc.value * T * 4u); });
+    static_for<0, DNAS_GROWS / 2>([&](auto mc) { if (__any((FT[2 * mc.value] | FT[2 * mc.value + 1]) != 0u)) pairUsed |= 1u << mc.value; });
+  }
 #define FOLD_DC(f) (((f) & 0xffffu) << 3)
 #define FOLD_SC(f) (((f) >> 16) << 3)
 #define FOLD_HAS_SC(f) ((f) != 0u && ((f) >> 16) != 0xffffu)
@@ -389,6 +396,11 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
         }
       }
       __syncthreads();
+      if (!arrived) {
+        // every member has OR-ed its XCC id into the census word before it bumped GE: one bit set = one XCD = one L2
+        const unsigned census = wLoad(&SY[40]);
+        onXcd = __builtin_amdgcn_readfirstlane((census & (census - 1u)) == 0u ? 1 : 0) != 0;
+      }
       arrived = true;
       aborted = *abortL != 0u;
     }
@@ -400,10 +412,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
   const int L = (int)(readOff[read + 1] - readOff[read]);
   double* const lat = arena + slotOff[r];
   double* const latM = lat + (size_t)member * NSm;   // this member's slots of a column
-  const unsigned redOff = kXRed + (unsigned)(((r - rFirst) / rStep) & 1) * 8u;
-  if constexpr (G_ > 1) {
-    if (member == 0 && tid == 0) xStore(xB, 0u, redOff, kNegInf);   // this read's reduction cell (last used two reads ago)
-  }
+  const unsigned redOff = kXRed + (unsigned)(((r - rFirst) / rStep) & 1) * ((unsigned)G_ + 15u & ~15u) * 8u;   // this read's reduction cells
 
   // Bounded-memory decode: this launch fills columns c0 .. c1 of the read only.  A segment that stops short of the read's
   // end leaves, next to its last column, what the next column's phase A needs besides S(c1): the T1 hand-over, in the D
@@ -446,7 +455,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
             if constexpr (kRows[k].gOut != 0) {
               if (kRows[k].gOut == 1 ? ENT_VALID(en) : ENT_GLOBAL(en)) {
                 if (kRows[k].kind == 1 || !ENT_GNULL(en))
-                  xMax(xBd, ENT_GCELL(en), kXA, (withScoreRow(kc, S[k], en) + a.noGap) + ldsRead(ldsB, subRow + ENT_GBASE32(en)));
+                  xStore(xB, onXcd, ENT_GCELL(en), kXA, (withScoreRow(kc, S[k], en) + a.noGap) + ldsRead(ldsB, subRow + ENT_GBASE32(en)));
                 return;
               }
               if constexpr (kRows[k].gOut == 1) return;
@@ -474,16 +483,16 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
       if constexpr (G_ > 1) {
         // what the other members offered lands in the LDS cells of the states it was meant for
         double xa[R_];
-        static_for<0, DNAS_GROWS>([&](auto rc) {   // all loads in flight together
-          xa[rc.value] = kNegInf;
-          if (FT[rc.value]) xa[rc.value] = xLoad(xB, tid8, kXA + X_OWN_U(rc.value));
+        static_for<0, DNAS_GROWS / 2>([&](auto mc) {   // all loads in flight together
+          constexpr int m2 = mc.value;
+          xa[2 * m2] = kNegInf; xa[2 * m2 + 1] = kNegInf;
+          if (pairUsed & (1u << m2)) xLoad2(kXA, mc, xa[2 * m2], xa[2 * m2 + 1]);
         });
-        static_for<0, DNAS_GROWS>([&](auto rc) {
-          constexpr int r = rc.value;
-          if (xa[r] > kNegInf) {
-            ldsMax(ldsB, FOLD_DC(FT[r]), xa[r]);
-            xStore(xB, tid8, kXA + X_OWN_U(r), kNegInf);      // nobody offers here again before the next column's barrier
-          }
+        static_for<0, DNAS_GROWS / 2>([&](auto mc) {
+          constexpr int m2 = mc.value;
+          if (xa[2 * m2] > kNegInf) ldsMax(ldsB, FOLD_DC(FT[2 * m2]), xa[2 * m2]);
+          if (xa[2 * m2 + 1] > kNegInf) ldsMax(ldsB, FOLD_DC(FT[2 * m2 + 1]), xa[2 * m2 + 1]);
+          if (xa[2 * m2] > kNegInf || xa[2 * m2 + 1] > kNegInf) xClear2(kXA, mc);      // nobody offers here again before the next column's barrier
         });
         __syncthreads();
       }
@@ -557,10 +566,13 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
         if constexpr (G_ > 1) { if (wv == 0) geNow = wLoad(&SY[0]); }
         auto loadInbox = [&](auto setc) {
           constexpr int q = setc.value;
-          static_for<0, DNAS_GROWS>([&](auto rc) {
-            constexpr int r = rc.value;
-            xd[q][r] = xLoad(xB, tid8, kXBd + X_OWN_U(r));
-            if constexpr (r < DNAS_GSROWS) xs[q][r] = xLoad(xB, tid8, kXBs + X_OWN_U(r));
+          static_for<0, DNAS_GROWS / 2>([&](auto mc) {
+            constexpr int m2 = mc.value;
+            if (pairUsed & (1u << m2)) {
+              xLoad2(kXBd, mc, xd[q][2 * m2], xd[q][2 * m2 + 1]);
+              if constexpr (2 * m2 + 1 < DNAS_GSROWS) xLoad2(kXBs, mc, xs[q][2 * m2], xs[q][2 * m2 + 1]);
+              else if constexpr (2 * m2 < DNAS_GSROWS) xs[q][2 * m2] = xLoad(xB, tid16, kXBs + X_PAIR_U(m2));
+            }
           });
         };
         auto foldInbox = [&](auto setc) {
@@ -612,10 +624,10 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
                   if (kRows[k].gOut == 1 || ENT_GLOBAL(en)) {
                     sentX = 1;
                     if (kRows[k].kind == 1 || (kRows[k].kind != 2 && !ENT_GNULL(en))) {
-                      xMax(xBd, ENT_GCELL(en), kXBd, withScoreRow(kc, xv, en));
+                      xStore(xB, onXcd, ENT_GCELL(en), kXBd, withScoreRow(kc, xv, en));
                     } else {                                           // viterbi.cpp:137-151
-                      xMax(xBd, ENT_GCELL(en), kXBd, withScoreRow(kc, d, en));
-                      xMax(xBd, ENT_GCELL(en), kXBs, withScoreRow(kc, s, en));
+                      xStore(xB, onXcd, ENT_GCELL(en), kXBd, withScoreRow(kc, d, en));
+                      xStore(xB, onXcd, ENT_GCELL(en), kXBs, withScoreRow(kc, s, en));
                     }
                     return;
                   }
@@ -736,7 +748,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
       static_for<0, DNAS_GROWS>([&](auto rc) {
         constexpr int r = rc.value;
         if (lastD[r] > kNegInf) xDirty |= 1u << r;
-        if constexpr (r < DNAS_GSROWS) { if (lastS[r] > kNegInf) xDirty |= 0x100u << r; }
+        if constexpr (r < DNAS_GSROWS) { if (lastS[r] > kNegInf) xDirty |= 0x10000u << r; }
       });
       __syncthreads();   // all waves are out of the sweeps before phase C clears the accumulators
       if constexpr (G_ > 1) {
@@ -764,10 +776,10 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
       if constexpr (G_ > 1) {
         // the inbox cells that were offered into are cleared for the next column's fixpoint (every offer was seen by
         // the last sweep; nobody offers into XB again before the next column's barrier)
-        static_for<0, DNAS_GROWS>([&](auto rc) {
-          constexpr int r = rc.value;
-          if (xDirty & (1u << r)) xStore(xB, tid8, kXBd + X_OWN_U(r), kNegInf);
-          if (xDirty & (0x100u << r)) xStore(xB, tid8, kXBs + X_OWN_U(r), kNegInf);
+        static_for<0, DNAS_GROWS / 2>([&](auto mc) {
+          constexpr int m2 = mc.value;
+          if (xDirty & (3u << (2 * m2))) xClear2(kXBd, mc);
+          if constexpr (2 * m2 < DNAS_GSROWS) { if (xDirty & (0x30000u << (2 * m2))) xClear2(kXBs, mc); }
         });
       }
       const int xn = pos < L ? seq[pos] : 0;
@@ -894,13 +906,18 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
   __syncthreads();
   if (tid == 0) {
     for (int w = 1; w < T / 64; ++w) best = dmax(best, red[w]);
-    if constexpr (G_ > 1) xMax(xBd, 0u, redOff, best);
+    if constexpr (G_ > 1) xStore(xB, onXcd, (unsigned)member * 8u, redOff, best);
     else { red[0] = best; outLoglike[read] = best; }
   }
   if constexpr (G_ > 1) {
     clusterBarrier();          // every member's best has landed (and the last column's accumulators are clear)
     if (aborted) break;
-    if (tid == 0) red[0] = xLoad(xB, 0u, redOff);
+    if (tid < 64) {
+      double b = tid < G_ ? xLoad(xB, tid8, redOff) : kNegInf;
+      for (int g = 64; g < G_; g += 64) b = dmax(b, tid + g < G_ ? xLoad(xB, tid8 + (unsigned)g * 8u, redOff) : kNegInf);
+      for (int off = 32; off > 0; off >>= 1) b = dmax(b, __shfl_down(b, off, 64));
+      if (tid == 0) red[0] = b;
+    }
   }
   __syncthreads();
   {

@@ -113,6 +113,7 @@ def lib():
         "dnas_tiera_precompile": (ctypes.c_int, [P(FlatModelC), ctypes.c_char_p, sz]),
         "dnas_tierc_precompile": (ctypes.c_int, [P(FlatModelC), ctypes.c_int32, ctypes.c_char_p, sz]),
         "dnas_tierc_plan": (ctypes.c_int, [P(FlatModelC), ctypes.c_int32, vp, vp, vp, sz, vp, vp, vp, vp, vp]),
+        "dnas_tierc_plan_proxies": (ctypes.c_int, [P(FlatModelC), ctypes.c_int32, vp, vp, sz]),
         "dnas_model_cluster_census": (ctypes.c_int, [vp, vp, vp]),
         "dnas_tune_record_name": (ctypes.c_int, [vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_char_p, ctypes.c_size_t]),
         "dnas_kernel_source_hash": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t]),

@@ -180,17 +180,20 @@ int dnas_tiera_precompile(const dnas_flat_model *fm, char *note, size_t note_cap
 /* Tier C: the same kernel run by a cluster of `members` work-groups per read (machines beyond one CU).
  * dnas_tierc_precompile compiles it ahead of time (members = 0: the smallest cluster that fits; no GPU needed).
  * dnas_tierc_plan is an analysis / test aid: the tables exactly as the kernel receives them.  info[8] =
- * {members, rows, threads, entries per member, S stripes, inbox rows, 0, 0}; the other outputs may be NULL:
+ * {members, rows, threads, entries per member, S stripes, inbox rows, proxies, 0}; the other outputs may be NULL:
  * row_shapes[rows][6] = {entries, S stripe, kind, class, full, entries into another member's inbox: 0 none /
  * 1 all / 2 mixed}, entries[members][entries][threads], meta[members][rows][threads], member_of[n_states],
  * lds_index[n_states] = row*threads + lane inside the member, lattice_slot[n_states],
- * fold[members][inbox rows][threads] = the LDS cells behind every inbox slot.
+ * fold[members][inbox rows][threads] = the LDS cells behind every inbox cell (one cell per edge between two members).
+ * dnas_tierc_plan_proxies: member and lds_index of the plan's proxies (places that hold no state of the machine: they
+ * combine the null edges of one member into one state of another and forward the maximum over ONE edge), info[6] of them.
  * members = 1 describes the tier-A plan.  dnas_model_cluster_census: clusters that ran in the last call and how
  * many of them had members on more than one XCD (placement is a speed matter only). */
 int dnas_tierc_precompile(const dnas_flat_model *fm, int32_t members, char *note, size_t note_cap);
 int dnas_tierc_plan(const dnas_flat_model *fm, int32_t members, int32_t *info, int32_t *row_shapes, uint32_t *entries,
                     size_t entries_cap, uint32_t *meta, int32_t *member_of, int32_t *lds_index, int32_t *lattice_slot,
                     uint32_t *fold);
+int dnas_tierc_plan_proxies(const dnas_flat_model *fm, int32_t members, int32_t *proxy_member, int32_t *proxy_lds_index, size_t cap);
 int dnas_model_cluster_census(dnas_model *model, int32_t *clusters, int32_t *split);
 /* The file name of a machine's row-program tuning record -- members = 1: as tier A (threads = 0: 1024); members = 0 or >= 2: as
  * tier C with the smallest / that cluster (threads as given to the model, 0 = the planner's choice) --: "tune_<hash>.txt", looked

@@ -192,6 +192,33 @@ def test_config4b_hamming74_water64_composite_tier_c(da, oracle_mod, ref_data):
     dec.close()
 
 
+@pytest.mark.parametrize("mach,fa,flags,members", [("s16mr2l4c4.json", "hello.s16mr2.fa", dict(global_=True), 3), ("s16h74l4c4.json", "hello.s16h74.del.fa", dict(), 4),
+                                                   ("s16h74l4c4.json", "hello.s16h74.del.fa", dict(global_=True), 2)])
+def test_tier_c_proxies_full_lattice_bit_exact(da, oracle_mod, ref_data, monkeypatch, mach, fa, flags, members):
+    """Where several null edges of one member end in the same state of another, the planner ends them at a PROXY inside the source
+    member and forwards their maximum over one edge (the 258 538-state composite: 2 245 edges into state 0 become 20).  Here from
+    two edges on (DNAS_PLAN_PROXY_MIN=2), so that the fixture machines have many: every lattice cell is still the oracle's."""
+    O = oracle_mod
+    monkeypatch.setenv("DNAS_PLAN_PROXY_MIN", "2")
+    path = os.path.join(ref_data, mach)
+    m = da.Machine.fromFile(path)
+    params = da.MutatorParams.fromFlags(**flags)
+    n_prox = len(da.FlatModel(m, params).cluster_plan(members)["proxy_member"])
+    assert n_prox > 0
+    dec = da.ViterbiDecoder(m, params, options="tier=C,cluster=%d" % members)
+    try:
+        orc = O.ViterbiOracle(O.Machine.from_file(path), O.MutatorParams.from_cli(**flags))
+        read = da.read_fastseqs(os.path.join(ref_data, fa))[0][1]
+        out, ll, st = dec.decode([read])
+        s, oll, olat = orc.decode(read, want_lattice=True)
+        lat = dec.lattice(0, len(read))
+        assert out[0] == s and ll[0] == oll and st[0] == 0
+        assert np.array_equal(np.ascontiguousarray(lat.transpose(0, 2, 1)).view(np.uint64), olat.view(np.uint64))
+        print("%s, %d members: %d proxies" % (mach, members, n_prox))
+    finally:
+        dec.close()
+
+
 @pytest.mark.parametrize("mach,fa,flags,members", [("s16h74l4c4.json", "hello.s16h74.del.fa", dict(global_=True), 4),
                                                    ("s16mr2l4c4.json", "hello.s16mr2.fa", dict(), 3)])
 def test_tier_c_clusters_split_over_xcds(da, oracle_mod, ref_data, mach, fa, flags, members):

@@ -24,11 +24,18 @@ def _decode_plan(fm, members):
     row_off = np.concatenate([[0], np.cumsum(np.maximum(shapes[:, 0], 0))])
     state_at = np.full((G, K * T), -1, dtype=np.int64)
     state_at[member_of, lds_idx] = np.arange(N)
-    assert (state_at >= 0).sum() == N, "two states share a place"
-    out = [[] for _ in range(N)]
-    for j in range(N):
-        g = int(member_of[j])
-        k, t = divmod(int(lds_idx[j]), T)
+    # proxies: places N, N+1, ... that hold no state of the machine -- a member's null edges into one state of another member end
+    # there, and ONE null edge of class 0 carries their maximum on (host/plan.cpp)
+    n_prox = len(pl["proxy_member"])
+    state_at[pl["proxy_member"], pl["proxy_lds_index"]] = N + np.arange(n_prox)
+    member_all = np.concatenate([member_of, pl["proxy_member"]])
+    lds_all = np.concatenate([lds_idx, pl["proxy_lds_index"]])
+    assert (state_at >= 0).sum() == N + n_prox, "two states share a place"
+    out = [[] for _ in range(N + n_prox)]
+    cells_seen = set()
+    for j in range(N + n_prox):
+        g = int(member_all[j])
+        k, t = divmod(int(lds_all[j]), T)
         assert shapes[k, 0] >= 0, "state placed in a row the plan marks empty"
         kind, cls_common, g_out = shapes[k, 2], shapes[k, 3], shapes[k, 5]
         for e in range(int(shapes[k, 0])):
@@ -41,10 +48,14 @@ def _decode_plan(fm, members):
             if en & 4:                                            # destination in another member's inbox
                 assert g_out in (1, 2)
                 cell = (en >> 3) & 0xfffff
-                dg, slot = divmod(cell, n_in * T)
+                assert cell not in cells_seen, "two edges share an inbox cell (a cell has ONE writer)"
+                cells_seen.add(cell)
+                dg, idx = divmod(cell, n_in * T)                  # cell (r, t) of a member sits at (r/2)*2T + 2t + (r&1)
+                pair, rem = divmod(idx, 2 * T)
+                r_in, t_in = 2 * pair + (rem & 1), rem // 2
                 assert dg != g, "inbox entry into the own member"
-                f = int(fold[dg, slot // T, slot % T])            # the fold table says which LDS cells the slot feeds
-                assert f != 0, "offer into an unused inbox slot"
+                f = int(fold[dg, r_in, t_in])                     # the fold table says which LDS cells the cell feeds
+                assert f != 0, "offer into an unused inbox cell"
                 dst_idx = ((f & 0xffff) * 8 - dc_base) // 8
                 dst = int(state_at[dg, dst_idx])
                 is_null = bool(en & 0x800000)
@@ -65,12 +76,20 @@ def _decode_plan(fm, members):
             assert dst >= 0, "entry points at an empty slot"
             assert kind == 0 or kind == (2 if is_null else 1)
             out[j].append((dst, cls, base, is_null))
+    for i in range(n_prox):                                       # a proxy forwards over one null edge that adds nothing, into another member
+        (dst, cls, _, is_null), = out[N + i]
+        assert is_null and cls == 0 and dst < N and member_of[dst] != pl["proxy_member"][i]
+        assert shapes[pl["proxy_lds_index"][i] // T, 1] >= 0, "a proxy needs an S cell"
+    for j in range(N):                                            # ... so that an edge into a proxy is an edge to the proxy's destination
+        for i, (dst, cls, base, is_null) in enumerate(out[j]):
+            if dst >= N:
+                assert is_null and member_of[j] == pl["proxy_member"][dst - N]
+                out[j][i] = (out[dst][0][0], cls, base, True)
+    out = out[:N]
     rows = lds_idx // T
     has_s = shapes[rows, 1] >= 0
-    # every used inbox slot belongs to exactly one state
-    used = fold[fold != 0] & 0xffff if G > 1 else np.zeros(0, dtype=np.uint32)
-    per_member = [sorted((fold[g][fold[g] != 0] & 0xffff).tolist()) for g in range(G)] if G > 1 else []
-    assert all(len(set(v)) == len(v) for v in per_member)
+    # every used inbox cell has a writer
+    assert G == 1 or int((fold != 0).sum()) == len(cells_seen)
     return out, has_s
 
 
