@@ -134,17 +134,24 @@ __device__ __forceinline__ double dmax(double a, double b) {
   asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
-__device__ __forceinline__ double ldsRead(const char* base, unsigned byteOff) {
-  return *reinterpret_cast<const double*>(base + byteOff);
+// LDS by byte address.  The kernel has no static LDS, so the dynamic block starts at address 0 (checked at kernel entry) and an
+// accumulator's address is the number the plan computed: no base is added to it.
+typedef __attribute__((address_space(3))) double lds_f64;
+__device__ __forceinline__ lds_f64* ldsAt(unsigned byteOff) { return (lds_f64*)(__UINTPTR_TYPE__)byteOff; }
+__device__ __forceinline__ double ldsRead(unsigned byteOff) { return *ldsAt(byteOff); }
+__device__ __forceinline__ void ldsWrite(unsigned byteOff, double v) { *ldsAt(byteOff) = v; }
+__device__ __forceinline__ void ldsMax(unsigned byteOff, double v) {
+  __hip_atomic_fetch_max(ldsAt(byteOff), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void ldsWrite(char* base, unsigned byteOff, double v) {
-  *reinterpret_cast<double*>(base + byteOff) = v;
+__device__ __forceinline__ double ldsMaxRtn(unsigned byteOff, double v) {   // returns what the cell held
+  return __hip_atomic_fetch_max(ldsAt(byteOff), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void ldsMax(char* base, unsigned byteOff, double v) {
-  __hip_atomic_fetch_max(reinterpret_cast<double*>(base + byteOff), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ double ldsMaxRtn(char* base, unsigned byteOff, double v) {   // returns what the cell held
-  return __hip_atomic_fetch_max(reinterpret_cast<double*>(base + byteOff), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+// the DC address of an entry, straight from its register (one instruction; the statement is volatile so that the 28+ decoded
+// addresses are not hoisted out of the column loop and kept in registers)
+__device__ __forceinline__ unsigned entDc(unsigned e) {
+  unsigned r;
+  asm volatile("v_and_b32 %0, 0x3fff8, %1" : "=v"(r) : "v"(e));
+  return r;
 }
 // Global memory is addressed the buffer way -- a uniform base in scalar registers (a resource descriptor), a 32-bit
 // per-lane byte offset and a uniform byte offset: the address arithmetic of the tables, the lattice columns and the
@@ -222,7 +229,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
   extern __shared__ unsigned ldsU[];
   constexpr int T = DNAS_T, K = DNAS_K, D_ = DNAS_D, lanes = 2, NSm = DNAS_NS, NS = DNAS_NS * DNAS_G;   // stored lanes: S, D
   const int tid = threadIdx.x;
-  char* const ldsB = reinterpret_cast<char*>(lds);
+  if ((unsigned)(unsigned long long)(void*)lds != 0u) __builtin_trap();   // (see ldsAt: byte addresses are absolute)
   const double* const subL = lds + (kTabBase / 8) + 4;
   // the vote words live in the same dynamic LDS block; a second extern array (same base) keeps
   // the accesses in the LDS address space (a volatile generic pointer would turn them into
@@ -297,7 +304,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
   auto withScore = [&](double v, unsigned cls) -> double {
     if constexpr (DNAS_NCLS <= 1) return v;
     else if constexpr (DNAS_NCLS == 2) return cls ? v + a.score[1] : v;
-    else return v + ldsRead(ldsB, kTabBase + cls * 8);
+    else return v + ldsRead(kTabBase + cls * 8);
   };
   // ... of an entry of row k: the row's common class is a compile-time constant
   auto withScoreRow = [&](auto kc, double v, unsigned en) -> double {
@@ -455,13 +462,13 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
             if constexpr (kRows[k].gOut != 0) {
               if (kRows[k].gOut == 1 ? ENT_VALID(en) : ENT_GLOBAL(en)) {
                 if (kRows[k].kind == 1 || !ENT_GNULL(en))
-                  xStore(xB, onXcd, ENT_GCELL(en), kXA, (withScoreRow(kc, S[k], en) + a.noGap) + ldsRead(ldsB, subRow + ENT_GBASE32(en)));
+                  xStore(xB, onXcd, ENT_GCELL(en), kXA, (withScoreRow(kc, S[k], en) + a.noGap) + ldsRead(subRow + ENT_GBASE32(en)));
                 return;
               }
               if constexpr (kRows[k].gOut == 1) return;
             }
             const bool emit = kRows[k].kind == 1 ? (kRows[k].full != 0 || ENT_VALID(en)) : ENT_EMIT(en);
-            if (emit) ldsMax(ldsB, ENT_DC(en), (withScoreRow(kc, S[k], en) + a.noGap) + ldsRead(ldsB, subRow + ENT_BASE32(en)));
+            if (emit) ldsMax(ENT_DC(en), (withScoreRow(kc, S[k], en) + a.noGap) + ldsRead(subRow + ENT_BASE32(en)));
           });
         }
       });
@@ -490,8 +497,8 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
         });
         static_for<0, DNAS_GROWS / 2>([&](auto mc) {
           constexpr int m2 = mc.value;
-          if (xa[2 * m2] > kNegInf) ldsMax(ldsB, FOLD_DC(FT[2 * m2]), xa[2 * m2]);
-          if (xa[2 * m2 + 1] > kNegInf) ldsMax(ldsB, FOLD_DC(FT[2 * m2 + 1]), xa[2 * m2 + 1]);
+          if (xa[2 * m2] > kNegInf) ldsMax(FOLD_DC(FT[2 * m2]), xa[2 * m2]);
+          if (xa[2 * m2 + 1] > kNegInf) ldsMax(FOLD_DC(FT[2 * m2 + 1]), xa[2 * m2 + 1]);
           if (xa[2 * m2] > kNegInf || xa[2 * m2 + 1] > kNegInf) xClear2(kXA, mc);      // nobody offers here again before the next column's barrier
         });
         __syncthreads();
@@ -499,8 +506,8 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
       static_for<0, K>([&](auto kc) {
         constexpr int k = kc.value;
         if constexpr (rowLive(k)) {
-          S[k] = dmax(ldsRead(ldsB, DC_OWN(k)), Dv[k]);   // Dv: T1(pos-1) + sub[ctx1][x_pos], left there by phase C
-          ldsWrite(ldsB, DC_OWN(k), kNegInf);
+          S[k] = dmax(ldsRead(DC_OWN(k)), Dv[k]);   // Dv: T1(pos-1) + sub[ctx1][x_pos], left there by phase C
+          ldsWrite(DC_OWN(k), kNegInf);
           Dv[k] = kFresh;
         }
       });
@@ -590,9 +597,9 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
           if (__any(anyNew)) {
             static_for<0, DNAS_GROWS>([&](auto rc) {
               constexpr int r = rc.value;
-              if (xd[q][r] != lastD[r]) { lastD[r] = xd[q][r]; if (ldsMaxRtn(ldsB, FOLD_DC(FT[r]), xd[q][r]) < xd[q][r]) changed = 1; }
+              if (xd[q][r] != lastD[r]) { lastD[r] = xd[q][r]; if (ldsMaxRtn(FOLD_DC(FT[r]), xd[q][r]) < xd[q][r]) changed = 1; }
               if constexpr (r < DNAS_GSROWS) {
-                if (xs[q][r] != lastS[r]) { lastS[r] = xs[q][r]; if (ldsMaxRtn(ldsB, FOLD_SC(FT[r]), xs[q][r]) < xs[q][r]) changed = 1; }
+                if (xs[q][r] != lastS[r]) { lastS[r] = xs[q][r]; if (ldsMaxRtn(FOLD_SC(FT[r]), xs[q][r]) < xs[q][r]) changed = 1; }
               }
             });
           }
@@ -618,6 +625,13 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
             Dv[k] = d;
             const double xv = dmax(d + a.delExtend, s + a.delOpen);    // viterbi.cpp:124
             static_for<0, rowOut(k)>([&](auto ec) {
+              if constexpr (kRows[k].kind == 1 && kRows[k].gOut == 0) {
+                // emit edges into LDS only: the address is all that is needed of the entry (an empty entry decodes to address 0,
+                // which is no accumulator)
+                const unsigned dc = entDc(E[o + ec.value]);
+                if (kRows[k].full != 0 || dc != 0u) ldsMax(dc, withScoreRow(kc, xv, kRows[k].cls < 0 ? ENTRY(o + ec.value) : 0u));
+                return;
+              }
               const unsigned en = ENTRY(o + ec.value);
               if (kRows[k].full != 0 || ENT_VALID(en)) {
                 if constexpr (kRows[k].gOut != 0) {
@@ -634,15 +648,15 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
                 }
                 if constexpr (kRows[k].gOut != 1) {
                   if constexpr (kRows[k].kind == 1) {
-                    ldsMax(ldsB, ENT_DC(en), withScoreRow(kc, xv, en));
+                    ldsMax(ENT_DC(en), withScoreRow(kc, xv, en));
                   } else if constexpr (kRows[k].kind == 2) {            // viterbi.cpp:137-151
-                    ldsMax(ldsB, ENT_DC(en), withScoreRow(kc, d, en));
-                    ldsMax(ldsB, ENT_SC(en), withScoreRow(kc, s, en));
+                    ldsMax(ENT_DC(en), withScoreRow(kc, d, en));
+                    ldsMax(ENT_SC(en), withScoreRow(kc, s, en));
                   } else if (ENT_EMIT(en)) {
-                    ldsMax(ldsB, ENT_DC(en), withScoreRow(kc, xv, en));
+                    ldsMax(ENT_DC(en), withScoreRow(kc, xv, en));
                   } else {
-                    ldsMax(ldsB, ENT_DC(en), withScoreRow(kc, d, en));
-                    ldsMax(ldsB, ENT_SC(en), withScoreRow(kc, s, en));
+                    ldsMax(ENT_DC(en), withScoreRow(kc, d, en));
+                    ldsMax(ENT_SC(en), withScoreRow(kc, s, en));
                   }
                 }
               }
@@ -654,8 +668,8 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
           if constexpr (G_ > 1 && !kSplit && k % kPollStride == 0) { foldInbox(IntC<0>{}); loadInbox(IntC<0>{}); }
           if constexpr (!rowLive(k)) return;
           double sc = kNegInf;
-          const double d = ldsRead(ldsB, DC_OWN(k));
-          if constexpr (kRows[k].sIdx >= 0) sc = ldsRead(ldsB, SC_OWN(k));
+          const double d = ldsRead(DC_OWN(k));
+          if constexpr (kRows[k].sIdx >= 0) sc = ldsRead(SC_OWN(k));
           rowEval(kc, d, sc);
         });
         ++rounds;
@@ -789,8 +803,8 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
         static_for<0, K>([&](auto kc) {
           constexpr int k = kc.value;
           if constexpr (rowLive(k)) {
-            ldsWrite(ldsB, DC_OWN(k), kNegInf);
-            if constexpr (kRows[k].sIdx >= 0) ldsWrite(ldsB, SC_OWN(k), kNegInf);
+            ldsWrite(DC_OWN(k), kNegInf);
+            if constexpr (kRows[k].sIdx >= 0) ldsWrite(SC_OWN(k), kNegInf);
           }
         });
         __syncthreads();
@@ -833,8 +847,8 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
           const double s = S[k];
           const int mdl = (int)(metaG[k - k0] & 15u);
           if constexpr (!kEarlyOffers) {
-            ldsWrite(ldsB, DC_OWN(k), kNegInf);
-            if constexpr (kRows[k].sIdx >= 0) ldsWrite(ldsB, SC_OWN(k), kNegInf);
+            ldsWrite(DC_OWN(k), kNegInf);
+            if constexpr (kRows[k].sIdx >= 0) ldsWrite(SC_OWN(k), kNegInf);
           }
           // T1(pos): chain from the deepest element (i = D-1) to i = 0.  Nearly every state has a
           // full context (mdl == D) and nearly every column a full history: that case is straight
@@ -850,7 +864,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
                 constexpr int i = D_ - 1 - jc.value;         // i = D-2 .. 0
                 double sp = s;
                 if constexpr (i > 0) sp = sh[k - k0][i - 1];
-                v = dmax(v + ldsRead(ldsB, kTabBase + 32 + ((metaG[k - k0] >> (4 + 2 * (i + 1))) & 3u) * 32 + xh[i] * 8),
+                v = dmax(v + ldsRead(kTabBase + 32 + ((metaG[k - k0] >> (4 + 2 * (i + 1))) & 3u) * 32 + xh[i] * 8),
                          (sp + a.tanDup) + a.len[i]);
               });
             }
