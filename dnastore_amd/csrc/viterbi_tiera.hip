@@ -629,7 +629,8 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
                 // emit edges into LDS only: the address is all that is needed of the entry (an empty entry decodes to address 0,
                 // which is no accumulator)
                 const unsigned dc = entDc(E[o + ec.value]);
-                if (kRows[k].full != 0 || dc != 0u) ldsMax(dc, withScoreRow(kc, xv, kRows[k].cls < 0 ? ENTRY(o + ec.value) : 0u));
+                const double v = withScoreRow(kc, xv, kRows[k].cls < 0 ? ENTRY(o + ec.value) : 0u);
+                if (kRows[k].full != 0 || dc != 0u) ldsMax(dc, v);
                 return;
               }
               const unsigned en = ENTRY(o + ec.value);
@@ -648,15 +649,17 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
                 }
                 if constexpr (kRows[k].gOut != 1) {
                   if constexpr (kRows[k].kind == 1) {
-                    ldsMax(ENT_DC(en), withScoreRow(kc, xv, en));
+                    const double v = withScoreRow(kc, xv, en);
+                    ldsMax(ENT_DC(en), v);
                   } else if constexpr (kRows[k].kind == 2) {            // viterbi.cpp:137-151
-                    ldsMax(ENT_DC(en), withScoreRow(kc, d, en));
-                    ldsMax(ENT_SC(en), withScoreRow(kc, s, en));
+                    const double vd = withScoreRow(kc, d, en), vs = withScoreRow(kc, s, en);
+                    ldsMax(ENT_DC(en), vd); ldsMax(ENT_SC(en), vs);
                   } else if (ENT_EMIT(en)) {
-                    ldsMax(ENT_DC(en), withScoreRow(kc, xv, en));
+                    const double v = withScoreRow(kc, xv, en);
+                    ldsMax(ENT_DC(en), v);
                   } else {
-                    ldsMax(ENT_DC(en), withScoreRow(kc, d, en));
-                    ldsMax(ENT_SC(en), withScoreRow(kc, s, en));
+                    const double vd = withScoreRow(kc, d, en), vs = withScoreRow(kc, s, en);
+                    ldsMax(ENT_DC(en), vd); ldsMax(ENT_SC(en), vs);
                   }
                 }
               }
