@@ -46,7 +46,7 @@ for name, m, payload, n_reads, members in machines:
         results.append((order, slack, min(ms[1:])))
     best = results[0]
     fastest = min(results, key=lambda r: r[2])
-    if fastest[2] < 0.985 * best[2]:
+    if fastest[2] < 0.96 * best[2]:      # the default dealing stays unless another is 4 % faster: the timings repeat to 1-3 %
         best = fastest
     text = "order=%d slack=%d kernel=%s   (fill of %d bench reads, %s;%s)\n" % (best[0], best[1], da.FlatModel.kernel_source_hash(), n_reads, name,
                                                                                "".join("  %d/%d: %.2f ms" % r for r in results))
