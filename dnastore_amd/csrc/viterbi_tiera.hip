@@ -624,12 +624,22 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
             S[k] = s;
             Dv[k] = d;
             const double xv = dmax(d + a.delExtend, s + a.delOpen);    // viterbi.cpp:124
+            // a row of one score class adds the score once, ahead of the first atomic, not per entry
+            constexpr bool oneCls = kRows[k].cls >= 0;
+            [[maybe_unused]] double xvC = xv, dC = d, sC = s;
+            if constexpr (oneCls && kRows[k].cls > 0) {
+              if constexpr (kRows[k].kind != 2) xvC = xv + a.score[kRows[k].cls];
+              if constexpr (kRows[k].kind != 1) { dC = d + a.score[kRows[k].cls]; sC = s + a.score[kRows[k].cls]; }
+            }
+            auto scored = [&](double plain, double withCls, unsigned en) -> double {
+              if constexpr (oneCls) return withCls; else return withScore(plain, ENT_CLS(en));
+            };
             static_for<0, rowOut(k)>([&](auto ec) {
               if constexpr (kRows[k].kind == 1 && kRows[k].gOut == 0) {
                 // emit edges into LDS only: the address is all that is needed of the entry (an empty entry decodes to address 0,
                 // which is no accumulator)
                 const unsigned dc = entDc(E[o + ec.value]);
-                const double v = withScoreRow(kc, xv, kRows[k].cls < 0 ? ENTRY(o + ec.value) : 0u);
+                const double v = scored(xv, xvC, oneCls ? 0u : ENTRY(o + ec.value));
                 if (kRows[k].full != 0 || dc != 0u) ldsMax(dc, v);
                 return;
               }
@@ -639,26 +649,26 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
                   if (kRows[k].gOut == 1 || ENT_GLOBAL(en)) {
                     sentX = 1;
                     if (kRows[k].kind == 1 || (kRows[k].kind != 2 && !ENT_GNULL(en))) {
-                      xStore(xB, onXcd, ENT_GCELL(en), kXBd, withScoreRow(kc, xv, en));
+                      xStore(xB, onXcd, ENT_GCELL(en), kXBd, scored(xv, xvC, en));
                     } else {                                           // viterbi.cpp:137-151
-                      xStore(xB, onXcd, ENT_GCELL(en), kXBd, withScoreRow(kc, d, en));
-                      xStore(xB, onXcd, ENT_GCELL(en), kXBs, withScoreRow(kc, s, en));
+                      xStore(xB, onXcd, ENT_GCELL(en), kXBd, scored(d, dC, en));
+                      xStore(xB, onXcd, ENT_GCELL(en), kXBs, scored(s, sC, en));
                     }
                     return;
                   }
                 }
                 if constexpr (kRows[k].gOut != 1) {
                   if constexpr (kRows[k].kind == 1) {
-                    const double v = withScoreRow(kc, xv, en);
+                    const double v = scored(xv, xvC, en);
                     ldsMax(ENT_DC(en), v);
                   } else if constexpr (kRows[k].kind == 2) {            // viterbi.cpp:137-151
-                    const double vd = withScoreRow(kc, d, en), vs = withScoreRow(kc, s, en);
+                    const double vd = scored(d, dC, en), vs = scored(s, sC, en);
                     ldsMax(ENT_DC(en), vd); ldsMax(ENT_SC(en), vs);
                   } else if (ENT_EMIT(en)) {
-                    const double v = withScoreRow(kc, xv, en);
+                    const double v = scored(xv, xvC, en);
                     ldsMax(ENT_DC(en), v);
                   } else {
-                    const double vd = withScoreRow(kc, d, en), vs = withScoreRow(kc, s, en);
+                    const double vd = scored(d, dC, en), vs = scored(s, sC, en);
                     ldsMax(ENT_DC(en), vd); ldsMax(ENT_SC(en), vs);
                   }
                 }
