@@ -770,8 +770,42 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const P
   p.nEntries = std::max(nEnt, 1);
   p.fillRatio = nEnt ? (double)real / ((double)nEnt * T * G) : 1.0;
 
+  // Which two rows of a thread share a 16-byte cell pair of the lattice.  A thread with a state in only ONE row of a pair
+  // still moves the pair with every store and history load; the rows of a program are not equally full (and not equally
+  // in every member), so rows 2m and 2m+1 as partners padded the lattice traffic of the bench machines by 13-16 %.  The
+  // rows are paired by fill instead: start from the rows sorted by their fill over all members, then swap partners
+  // between two pairs as long as the sum over members of |fill(a) - fill(b)| goes down (K <= 28: a few hundred trials).
+  std::vector<int> pairRows(K), pairSlot(K);     // pairRows[2m], [2m+1]: the rows of pair m; pairSlot[row] = 2m + side
+  {
+    std::vector<std::vector<long>> fill(G, std::vector<long>(K, 0));
+    for (int j = 0; j < N0; ++j) ++fill[part[j]][rowOfState[j]];
+    auto waste = [&](int a2, int b2) { long w = 0; for (int g = 0; g < G; ++g) w += std::labs(fill[g][a2] - fill[g][b2]); return w; };
+    for (int k = 0; k < K; ++k) pairRows[k] = k;
+    if (G > 1 && !getenv("DNAS_PLAN_NO_PAIRING")) {   // (one work-group per read keeps rows 2m, 2m+1: measured, its kernel is 1 % slower otherwise)
+      auto total = [&](int k) { long t = 0; for (int g = 0; g < G; ++g) t += fill[g][k]; return t; };
+      std::stable_sort(pairRows.begin(), pairRows.end(), [&](int a2, int b2) { return total(a2) > total(b2); });
+      for (bool better = true; better;) {
+        better = false;
+        for (int m = 0; m + 1 < K / 2; ++m)
+          for (int n = m + 1; n < K / 2; ++n) {
+            int& a2 = pairRows[2 * m]; int& b2 = pairRows[2 * m + 1]; int& c2 = pairRows[2 * n]; int& d2 = pairRows[2 * n + 1];
+            const long now = waste(a2, b2) + waste(c2, d2);
+            if (waste(a2, c2) + waste(b2, d2) < now) { std::swap(b2, c2); better = true; }
+            else if (waste(a2, d2) + waste(b2, c2) < now) { std::swap(b2, d2); better = true; }
+          }
+      }
+      // tidy: the lower row first inside a pair, the pairs by their first row
+      std::vector<std::pair<int, int>> ps;
+      for (int m = 0; m < K / 2; ++m) ps.emplace_back(std::min(pairRows[2 * m], pairRows[2 * m + 1]), std::max(pairRows[2 * m], pairRows[2 * m + 1]));
+      std::sort(ps.begin(), ps.end());
+      for (int m = 0; m < K / 2; ++m) { pairRows[2 * m] = ps[(size_t)m].first; pairRows[2 * m + 1] = ps[(size_t)m].second; }
+    }
+    for (int i = 0; i < K; ++i) pairSlot[pairRows[i]] = i;
+    p.pairRows.assign(pairRows.begin(), pairRows.end());
+  }
+
   // index spaces: a member's LDS index row*T + lane (consecutive lanes -> consecutive bank pairs), and
-  // the lattice slot member*K*T + (row/2)*2T + 2*lane + (row&1) used in HBM and by the traceback
+  // the lattice slot member*K*T + pair*2T + 2*lane + side used in HBM and by the traceback
   p.memberOf.assign(part.begin(), part.begin() + N0);
   p.slotOf.assign(N, -1);
   p.stateOf.assign((size_t)p.NS, -1);       // by (member*K + row)*T + lane
@@ -779,7 +813,7 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const P
     const int row = rowOfState[j], lane = laneOf[j];
     if (j < N0) p.stateOf[((size_t)part[j] * K + row) * T + lane] = j;      // (a proxy's place holds no state of the machine)
     else { p.proxyMember.push_back(part[j]); p.proxyLds.push_back(row * T + lane); }
-    p.slotOf[j] = part[j] * p.NSm + (row >> 1) * 2 * T + 2 * lane + (row & 1);
+    p.slotOf[j] = part[j] * p.NSm + (pairSlot[row] >> 1) * 2 * T + 2 * lane + (pairSlot[row] & 1);
   }
   p.slotOf.resize(N0);
 
@@ -851,9 +885,18 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const P
   }
   defs << "-DDNAS_T=" << T << "\n-DDNAS_K=" << K << "\n-DDNAS_D=" << D << "\n-DDNAS_NS=" << p.NSm << "\n-DDNAS_SROWS=" << p.nSRows
        << "\n-DDNAS_NCLS=" << p.nClasses << "\n-DDNAS_G=" << G << "\n-DDNAS_GROWS=" << nInboxRows << "\n-DDNAS_GSROWS=" << nInboxSRows << "\n-DDNAS_ROWS=" << rows.str();
+  {
+    bool identity = true;
+    for (int i = 0; i < K; ++i) identity = identity && p.pairRows[(size_t)i] == i;
+    if (!identity) {
+      defs << "\n-DDNAS_PAIRS=";
+      for (int i = 0; i < K; ++i) defs << (i ? "," : "") << p.pairRows[(size_t)i];
+    }
+  }
   p.defines = defs.str();
   p.key = "T" + std::to_string(T) + "K" + std::to_string(K) + "D" + std::to_string(D) + "S" + std::to_string(p.nSRows) + "C" +
           std::to_string(p.nClasses) + "G" + std::to_string(G) + "X" + std::to_string(nInboxRows) + "x" + std::to_string(nInboxSRows) + "R" + rows.str();
+  if (p.defines.find("-DDNAS_PAIRS=") != std::string::npos) p.key += "P" + p.defines.substr(p.defines.find("-DDNAS_PAIRS=") + 13);
   p.ok = true;
   return p;
 }

@@ -51,6 +51,7 @@ struct TierAPlan {
   std::vector<int32_t> stateOf;   // [G*K*T] index (member*K + row)*T + thread -> state or -1
   std::vector<uint32_t> entTab;   // [G][nEntries][T]  out-edges, see viterbi_tiera.hip
   std::vector<uint32_t> metaTab;  // [G][K][T]  mdl | ctx<<4 | flags
+  std::vector<int32_t> pairRows;  // [K] the rows of lattice cell pair m: pairRows[2m], pairRows[2m+1]
   std::vector<int32_t> proxyMember, proxyLds;   // cluster proxies (plan.cpp): member and row*T + lane of each
   std::vector<uint32_t> foldTab;  // [G][nGRows][T]  inbox slot -> LDS cells of its state (DC addr >> 3 | SC addr >> 3 << 16), 0: unused
   double score[4] = {0, 0, 0, 0};
@@ -64,7 +65,7 @@ struct TierAPlan {
   long exchangeStride() const { return 3 * exchangeCells() + 2 * ((G + 15) & ~15); }   // doubles per cluster: XA.dc | XB.dc | XB.sc | reduction cells (viterbi_tiera.hip kXStride)
 };
 
-constexpr int kPlanVersion = 5;      // bumped when the planner changes what it produces: recorded tuning verdicts name it
+constexpr int kPlanVersion = 6;      // bumped when the planner changes what it produces: recorded tuning verdicts name it
 
 // What the caller (a tuning record, an option, an experiment) decides about the row program; -1: as the environment says
 // (DNAS_PLAN_ORDER, DNAS_PLAN_SLACK), else the default.

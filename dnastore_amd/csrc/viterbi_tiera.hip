@@ -68,6 +68,20 @@ constexpr int kEntries = rowOffset(DNAS_K) > 0 ? rowOffset(DNAS_K) : 1;
 
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 static_assert(DNAS_K % 2 == 0, "rows come in pairs");
+// Which two rows of a thread share a 16-byte cell pair of the lattice (DNAS_PAIRS = a0,b0,a1,b1,...: the plan pairs rows that
+// are about equally full, so that few threads move a pair for one state; default: rows 2m and 2m+1).
+#ifdef DNAS_PAIRS
+constexpr int kPairRows[DNAS_K] = {DNAS_PAIRS};
+#else
+struct PairIdentity { int v[DNAS_K]; constexpr PairIdentity() : v() { for (int i = 0; i < DNAS_K; ++i) v[i] = i; } };
+constexpr PairIdentity kPairIdentity{};
+#define kPairRows kPairIdentity.v
+#endif
+constexpr int pairRow(int m2, int side) { return kPairRows[2 * m2 + side]; }
+constexpr int pairSlotOfRow(int k) {      // 2 * pair + side of row k
+  for (int i = 0; i < DNAS_K; ++i) if (kPairRows[i] == k) return i;
+  return -1;
+}
 
 template <int V> struct IntC { static constexpr int value = V; };
 template <int I, int N, class F>
@@ -161,8 +175,9 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ rsrc_t makeRsrc(const void* base) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)0xffffffffu, 0x00020000);   // raw buffer, no range to speak of
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)0x80000000u, 0x00020000);   // raw buffer; a lane whose offset is kLaneOff is out of range: it reads 0 and touches no memory
 }
+constexpr unsigned kLaneOff = 0x80000000u;
 constexpr int kAuxNt = 2, kAuxSc1 = 16;   // cache policy bits of a buffer access (gfx940+: bit 0 sc0, bit 1 nt, bit 4 sc1)
 __device__ __forceinline__ unsigned bufLoadU32(rsrc_t r, unsigned laneOff, unsigned uniOff) {
   return __builtin_amdgcn_raw_buffer_load_b32(r, (int)laneOff, (int)uniOff, 0);
@@ -348,7 +363,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
       constexpr int m2 = mc.value;                                                               \
       if (pairValid & (1u << m2)) {                                                              \
         dbl2 v2;                                                                                 \
-        v2.x = REG[2 * m2]; v2.y = REG[2 * m2 + 1];                                              \
+        v2.x = REG[pairRow(m2, 0)]; v2.y = REG[pairRow(m2, 1)];                                  \
         /* the D lane is not read again by this kernel: past the caches */                       \
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v2), colp, (int)tid16, (int)PAIR_OFF(lane, m2), \
                                                ((lane) == 1 && DNAS_NT_D) ? kAuxNt : 0);         \
@@ -365,12 +380,12 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
       v2.x = kNegInf; v2.y = kNegInf;                                                            \
       if (pairValid & (1u << m2))                                                                \
         v2 = __builtin_bit_cast(dbl2, __builtin_amdgcn_raw_buffer_load_b128(colp, (int)tid16, (int)PAIR_OFF(lane, m2), 0)); \
-      REG[2 * m2] = v2.x; REG[2 * m2 + 1] = v2.y;                                                \
+      REG[pairRow(m2, 0)] = v2.x; REG[pairRow(m2, 1)] = v2.y;                                    \
     });                                                                                          \
   }
   unsigned pairValid = 0;   // bit m: the lattice pair (rows 2m, 2m+1) of this thread holds a real state
   static_for<0, K / 2>([&](auto mc) {
-    if ((META(2 * mc.value) | META(2 * mc.value + 1)) & 0x20000000u) pairValid |= 1u << mc.value;
+    if ((META(pairRow(mc.value, 0)) | META(pairRow(mc.value, 1))) & 0x20000000u) pairValid |= 1u << mc.value;
   });
 
   // ---- cluster synchronisation (tier C).  GE only grows.  geBase = its value when the cluster last agreed
@@ -825,10 +840,92 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
       }
       int xh[D_ > 0 ? D_ : 1];   // xh[i] = x_{pos-i}
       static_for<0, D_>([&](auto ic) { xh[ic.value] = pos - ic.value >= 1 ? seq[pos - ic.value - 1] : 0; });
-      // rows 2m, 2m+1 of a thread are neighbours in the lattice: 16-byte loads and stores
+      // the two rows of a cell pair are neighbours in the lattice: 16-byte loads and stores
 #ifndef DNAS_CGROUP
 #define DNAS_CGROUP 4
 #endif
+      if constexpr (G_ > 1) {
+      // clusters: the rows of a cell pair are the plan's choice (DNAS_PAIRS), and a thread without a state in a pair loads nothing
+      constexpr int GP = DNAS_CGROUP / 2;          // cell pairs per load group
+      static_assert(GP >= 1, "a load group is at least one pair");
+      static_for<0, (K / 2 + GP - 1) / GP>([&](auto gc) {
+        constexpr int p0 = gc.value * GP, p1 = (p0 + GP < K / 2) ? p0 + GP : K / 2;
+        unsigned metaG[2 * GP];
+        static_for<2 * p0, 2 * p1>([&](auto qc) {   // (address rebuilt here: 14 hoisted pointers would cost 28 registers)
+          constexpr int k = kPairRows[qc.value];
+          metaG[qc.value - 2 * p0] = rowLive(k) ? META(k) : 0u;
+        });
+        double sh[2 * GP][D_ > 1 ? D_ - 1 : 1];
+        // clusters: a thread without a state in a pair is switched off by its offset (it reads 0, which nobody uses, and moves no
+        // bytes) -- formed here, from an opaque copy of the mask, so that the fourteen offsets are not kept in registers
+        {
+          const unsigned pv = opaque(pairValid);
+          static_for<p0, p1>([&](auto mc) {
+            constexpr int m2 = mc.value;
+            if constexpr (!rowLive(pairRow(m2, 0)) && !rowLive(pairRow(m2, 1))) return;
+            const unsigned off = (pv & (1u << m2)) ? tid16 : kLaneOff;
+            static_for<1, D_>([&](auto ic) {
+              constexpr int i = ic.value;
+              if (pos - i >= 1) {
+                // the oldest column is read for the last time: stream it past the caches
+                const dbl2 v2 = __builtin_bit_cast(dbl2, __builtin_amdgcn_raw_buffer_load_b128(COL_RSRC(pos - i), (int)off, (int)PAIR_OFF(0, m2),
+                                                                                                (DNAS_NT_H && i >= D_ - DNAS_NT_H) ? kAuxNt : 0));
+                sh[2 * (m2 - p0)][i - 1] = v2.x;
+                sh[2 * (m2 - p0) + 1][i - 1] = v2.y;
+              }
+            });
+          });
+        }
+        if constexpr (kEarlyOffers && gc.value == 0) {
+          if (earlyOffered) emitOffers(xn);       // column pos + 1: ((S(pos) + score) + noGap) + sub[base][x_{pos+1}]
+        }
+        static_for<2 * p0, 2 * p1>([&](auto qc) {
+          constexpr int k = kPairRows[qc.value], q = qc.value - 2 * p0;
+          if constexpr (!rowLive(k)) { Dv[k] = kNegInf; return; }
+          const double s = S[k];
+          const int mdl = (int)(metaG[q] & 15u);
+          if constexpr (!kEarlyOffers) {
+            ldsWrite(DC_OWN(k), kNegInf);
+            if constexpr (kRows[k].sIdx >= 0) ldsWrite(SC_OWN(k), kNegInf);
+          }
+          // T1(pos): chain from the deepest element (i = D-1) to i = 0.  Nearly every state has a
+          // full context (mdl == D) and nearly every column a full history: that case is straight
+          // line code, chosen per wave.
+          const bool valid = (metaG[q] & 0x20000000u) != 0;
+          double v = kNegInf;
+          if (pos >= D_ && __all(mdl == D_ || !valid)) {
+            if constexpr (D_ > 0) {
+              double sd = s;
+              if constexpr (D_ > 1) sd = sh[q][D_ - 2];
+              v = (sd + a.tanDup) + a.len[D_ - 1];
+              static_for<1, D_>([&](auto jc) {
+                constexpr int i = D_ - 1 - jc.value;         // i = D-2 .. 0
+                double sp = s;
+                if constexpr (i > 0) sp = sh[q][i - 1];
+                v = dmax(v + ldsRead(kTabBase + 32 + ((metaG[q] >> (4 + 2 * (i + 1))) & 3u) * 32 + xh[i] * 8),
+                         (sp + a.tanDup) + a.len[i]);
+              });
+            }
+          } else {
+            static_for<0, D_>([&](auto jc) {
+              constexpr int i = D_ - 1 - jc.value;           // lane q = i at column p = pos - i
+              if (i < mdl && pos - i >= 1) {
+                double sp = s;
+                if constexpr (i > 0) sp = sh[q][i - 1];
+                const double base = (sp + a.tanDup) + a.len[i];
+                if (i + 1 < mdl && pos - i - 1 >= 1)
+                  v = dmax(v + subL[((metaG[q] >> (4 + 2 * (i + 1))) & 3u) * 4 + xh[i]], base);
+                else
+                  v = base;
+              }
+            });
+          }
+          // next column: S >= T1(pos) + sub[ctx1][x_{pos+1}]   (viterbi.cpp:101-103)
+          Dv[k] = (valid && mdl > 0) ? v + subL[((metaG[q] >> 4) & 3u) * 4 + xn] : kNegInf;   // D(pos) is already on its way to HBM
+        });
+      });
+      } else {
+      // one work-group per read: rows 2m, 2m+1 are the pairs, every thread loads (switching threads off costs more than the bytes)
       constexpr int G = DNAS_CGROUP;               // rows per load group (even: whole pairs)
       static_for<0, (K + G - 1) / G>([&](auto gc) {
         constexpr int k0 = gc.value * G, k1 = (k0 + G < K) ? k0 + G : K;
@@ -899,6 +996,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
           Dv[k] = (valid && mdl > 0) ? v + subL[((metaG[k - k0] >> 4) & 3u) * 4 + xn] : kNegInf;   // D(pos) is already on its way to HBM
         });
       });
+      }
       // the S lane goes out last: a wave's memory operations return in order, so a store issued
       // between two groups would sit in front of the next group's history loads
       STORE_LANE(pos, 0, S)
@@ -921,7 +1019,6 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
   // ---- loglike (viterbi.h:102); local mode overwrites the end state with the column max
   // (viterbi.cpp:171-173).  bit30 of meta marks the reference's last state.
   double* const red = lds + (kTabBase / 8) + 28;
-  double* const lastS = latM + (size_t)L * lanes * NS;
   double best = kNegInf;
   static_for<0, K>([&](auto kc) {
     constexpr int k = kc.value;
@@ -957,8 +1054,10 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
           // the reference overwrites S(N-1, L) AFTER the duplication lanes of the last column were formed
           // from it (viterbi.cpp:161-173); those lanes are not stored here, so the value they came from is
           // kept in the spare cell behind the read's lattice for whoever rebuilds them (expand_lattice_kernel)
-          lat[(size_t)(L + 1) * lanes * NS] = S[k];
-          lastS[(k >> 1) * 2 * T + 2 * tid + (k & 1)] = red[0];
+          // (buffer stores: the two addresses live in scalar registers, not in a vector register pair kept for the whole read)
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, S[k]), makeRsrc(lat + (size_t)(L + 1) * lanes * NS), 0, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, red[0]), COL_RSRC(L), (int)tid16,
+                                                (int)(PAIR_OFF(0, pairSlotOfRow(k) >> 1) + (unsigned)(pairSlotOfRow(k) & 1) * 8u), 0);
         }
       }
     });

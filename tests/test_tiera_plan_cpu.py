@@ -221,7 +221,13 @@ def test_plan_row_program_invariants(ref_data):
         assert len(set(lds_idx.tolist())) == N and lds_idx.min() >= 0 and lds_idx.max() < K * T
         assert len(set(lat_slot.tolist())) == N
         rows, lanes = lds_idx // T, lds_idx % T
-        assert np.array_equal(lat_slot, (rows // 2) * 2 * T + 2 * lanes + (rows & 1))
+        # lattice slot = pair * 2T + 2 * lane + side: every row is one side of one cell pair (the plan pairs rows by their fill)
+        pair_side = (lat_slot // (2 * T)) * 2 + (lat_slot & 1)
+        assert np.array_equal((lat_slot % (2 * T)) // 2, lanes)
+        row_of = {}
+        for r, q in zip(rows.tolist(), pair_side.tolist()):
+            assert row_of.setdefault(q, r) == r, "two rows share a side of a cell pair"
+        assert len(set(row_of.values())) == len(row_of) and max(row_of) < K
         assert sorted(s for s in shapes[:, 1] if s >= 0) == list(range(n_s))
         valid = (meta >> 29) & 1
         assert int(valid.sum()) == N

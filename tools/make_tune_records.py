@@ -1,12 +1,12 @@
 """Row-program verdicts for the fixture and bench machines, from bench-like reads: for every machine the candidate programs
 (dealing order 1, order 2 with every slack share 0 .. 8: options plan_order, plan_slack) decode 2160 reads (three launches) -- encoded random payloads with
 1 % substitutions, as bench.py makes them -- three times; the fastest fill of the last two runs counts, and a candidate has
-to beat the default (order=1) by 1.5 %.  The records go to the directory given (tools/make_tune_records.sh copies them
+to beat the default (order=1) by 4 %.  The records go to the directory given (tools/make_tune_records.sh copies them
 to dnastore_amd/tune/, where the library finds them); their names hash the machine and the planner version, and each names the
 kernel source it was measured with (tests/test_tune_records.py fails when that is no longer the library's).  (The library's own tuning run, for machines without a record, has no encoder at
 hand and uses what a random walk through the machine emits; for s16h74l4c4 that ranks the two dealing orders the other way
 round than real reads do, by 2 % either way.)
-  python tools/make_tune_records.py <output directory>"""
+  python tools/make_tune_records.py <output directory> [--no-4b] [--only <part of a machine's name>]"""
 import os, sys, random
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -26,6 +26,8 @@ machines.append(("configs[1], 46 670 states", wl["machine"], wl["payload_bytes"]
 if "--no-4b" not in sys.argv:
     wl = bench.workload(da, 3, "b")
     machines.append(("configs[3] as written, 258 538 states", wl["machine"], wl["payload_bytes"], 16, 0))
+if "--only" in sys.argv:                         # one machine again, e.g. --only s16h74l4c4
+    machines = [mm for mm in machines if sys.argv[sys.argv.index("--only") + 1] in mm[0]]
 params = da.MutatorParams.fromFlags(global_=True)
 for name, m, payload, n_reads, members in machines:
     # tier A: three launches -- the traceback of one runs beside the fill of the next, as in a long job; clusters: one
