@@ -8,7 +8,7 @@ BASELINE.json `configs`; the default, 2, is the configuration the metric is quot
   2  10 000 x ~490-nt reads per GPU through s16h74l4c4.json (12 361 states), --error-global  [headline]
   3  ~1 kb reads through water64.1 * l4c4 (7 066 states: the composable reading of "water64.1 + hamming74", SURVEY
      8d 4a), 12 500 reads per GPU (100k over 8 GPUs); `--variant b`: hamming74 * dropdot * water64.1 * l4c4
-     (258 538 states, tier C), 16 reads per GPU
+     (258 538 states, tier C), 24 reads per GPU (two launches of 12 clusters)
   4  forward-backward E-step (expectedCounts, fwdback.cpp:190-209), 256-nt pairs with dup + sub + del errors,
      125 000 pairs per GPU (1M over 8 GPUs); unit nt/s over the read (output) lengths
 
@@ -61,7 +61,7 @@ def workload(da, config, variant):
                     name="configs[2]: ~490-nt reads through s16h74l4c4.json (12361 states)")
     if config == 3 and variant == "b":
         return dict(machine=_compose(da, "hamming74.json", da.Machine.fromJSON(DROPDOT), "water64.1.json", "l4c4.json"), payload_bytes=32,
-                    default_reads=16, name="configs[3] as written: ~1050-nt reads through hamming74*dropdot*water64.1*l4c4 (258538 states)")
+                    default_reads=24, name="configs[3] as written: ~1050-nt reads through hamming74*dropdot*water64.1*l4c4 (258538 states)")
     if config == 3:
         return dict(machine=_compose(da, "water64.1.json", "l4c4.json"), payload_bytes=56, default_reads=12500,
                     name="configs[3] (4a): ~1050-nt reads through water64.1*l4c4 (7066 states)")
@@ -421,7 +421,7 @@ def main():
         for name, fn in (
                 ("configs[1]", lambda: viterbi_line(ctx, 1, "a", 64, 1, 1, 4.0)),
                 ("configs[3] (water64.1*l4c4)", lambda: viterbi_line(ctx, 3, "a", 6255, 1, 1, 4.0)),
-                ("configs[3] as written (hamming74*dropdot*water64.1*l4c4)", lambda: viterbi_line(ctx, 3, "b", 16, 1, 0, 4.0)),
+                ("configs[3] as written (hamming74*dropdot*water64.1*l4c4)", lambda: viterbi_line(ctx, 3, "b", 24, 1, 0, 4.0)),
                 ("configs[4]", lambda: bench_fwdback.fwdback_line(ctx, 0, 2, 1, 4.0, False))):
             t1 = time.perf_counter()
             try:

@@ -25,7 +25,7 @@ wl = bench.workload(da, 1, "a")
 machines.append(("configs[1], 46 670 states", wl["machine"], wl["payload_bytes"], 64, 0))
 if "--no-4b" not in sys.argv:
     wl = bench.workload(da, 3, "b")
-    machines.append(("configs[3] as written, 258 538 states", wl["machine"], wl["payload_bytes"], 16, 0))
+    machines.append(("configs[3] as written, 258 538 states", wl["machine"], wl["payload_bytes"], 24, 0))
 if "--only" in sys.argv:                         # one machine again, e.g. --only s16h74l4c4
     machines = [mm for mm in machines if sys.argv[sys.argv.index("--only") + 1] in mm[0]]
 params = da.MutatorParams.fromFlags(global_=True)
