@@ -13,7 +13,7 @@ log "profiles"
 bash tools/profile_round3.sh config2 --config 2 --reads 4320
 bash tools/profile_round3.sh config1 --config 1 --reads 64
 bash tools/profile_round3.sh config3 --config 3 --reads 2160
-bash tools/profile_round3.sh config3b --config 3 --variant b --reads 8
+bash tools/profile_round3.sh config3b --config 3 --variant b --reads 12
 bash tools/profile_round3.sh config4 --config 4 --reads 125000
 log "sq counters tier C"
 bash tools/sq_counters.sh c > $P/sq_c.log 2>&1
@@ -28,5 +28,5 @@ timeout -k 10 900 python bench.py --config 4 --reads 1000000 --steps 2 --warmup 
 log "bulk parity"
 timeout -k 10 600 python tools/bulk_parity.py 2000 14 > $P/bulk_parity.txt 2>&1 || log "bulk parity FAILED"
 timeout -k 10 600 python tools/bulk_parity.py 96 14 --config 1 > $P/bulk_parity_config1.txt 2>&1 || log "bulk parity config1 FAILED"
-timeout -k 10 900 python tools/bulk_parity.py 16 14 --config 3 --variant b > $P/bulk_parity_config3b.txt 2>&1 || log "bulk parity config3b FAILED"
+timeout -k 10 900 python tools/bulk_parity.py 24 14 --config 3 --variant b > $P/bulk_parity_config3b.txt 2>&1 || log "bulk parity config3b FAILED"
 log "done"
