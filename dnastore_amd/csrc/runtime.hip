@@ -68,7 +68,7 @@ struct TierALaunch {
   unsigned long long timeoutTicks;
   unsigned long long arriveTicks;
   const int* colRange;          // bounded-memory decode: [nReads][2] first and last column of this launch (null: whole reads)
-  int spread;                   // tier C: 1 = a cluster's members are neighbouring blocks (spread over the XCDs; option cluster_spread, tests)
+  int spread;                   // tier C: 1 = a cluster's members are neighbouring blocks (dealt over the XCDs; option cluster_spread)
 };
 
 struct dnas_model {
@@ -91,7 +91,7 @@ struct dnas_model {
   unsigned* dFoldTab = nullptr; // tier C: inbox slot -> LDS cells, per member
   size_t xStride = 0;           // doubles per cluster in dXbuf
   unsigned long long timeoutTicks = 0, arriveTicks = 0;
-  int clusterSpread = 0;        // option cluster_spread=1: members of a cluster on different XCDs (a test of the protocol, slower)
+  int clusterSpread = 0;        // members of a cluster dealt over the XCDs (option cluster_spread; default: when that fits a quarter more clusters)
   unsigned* syncCheck = nullptr;     // pinned host copies of the sync blocks of every launch of the last call (watchdog, placement census)
   size_t syncCheckWords = 0, syncCheckCap = 0;
   size_t syncLaunches = 0;
