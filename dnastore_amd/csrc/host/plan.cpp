@@ -893,10 +893,22 @@ TierAPlan buildPlan(const dnas_flat_model& fm, const int G, const int T, const P
       for (int i = 0; i < K; ++i) defs << (i ? "," : "") << p.pairRows[(size_t)i];
     }
   }
+  // Small row programs (water64.1*l4c4: 8 rows, 12 entries, 66 KB of LDS) leave half a CU idle: compiled for 64 registers per
+  // thread, two work-groups of 1024 threads share a CU and hide each other's waits (measured on MI355X: 0.41 -> 0.565 of the
+  // roofline; phase C then loads one cell pair at a time).  DNAS_PLAN_OCCUPANCY=1 / 2 overrides the rule.
+  {
+    bool two = G == 1 && T == 1024 && K <= 8 && p.nEntries <= 14 && 2 * (p.ldsBytes + 1024) <= 160 * 1024;
+    if (const char* e = getenv("DNAS_PLAN_OCCUPANCY")) two = atoi(e) == 2 && G == 1 && T == 1024 && 2 * (p.ldsBytes + 1024) <= 160 * 1024;
+    if (two) {
+      p.wavesPerSimd = 8;
+      defs << "\n-DDNAS_WAVES_PER_EU=8\n-DDNAS_CGROUP=2";
+    }
+  }
   p.defines = defs.str();
   p.key = "T" + std::to_string(T) + "K" + std::to_string(K) + "D" + std::to_string(D) + "S" + std::to_string(p.nSRows) + "C" +
           std::to_string(p.nClasses) + "G" + std::to_string(G) + "X" + std::to_string(nInboxRows) + "x" + std::to_string(nInboxSRows) + "R" + rows.str();
   if (p.defines.find("-DDNAS_PAIRS=") != std::string::npos) p.key += "P" + p.defines.substr(p.defines.find("-DDNAS_PAIRS=") + 13);
+  if (p.wavesPerSimd) p.key += "W" + std::to_string(p.wavesPerSimd);
   p.ok = true;
   return p;
 }

@@ -61,6 +61,8 @@ struct TierAPlan {
   int backEdgesOnWalk = 0;        // most backward edges (destination row <= source row, or another member) on any walk of 30 edges
   double sameWave = 0;            // share of forward edges whose ends sit in the same wave
   double crossEdges = 0;          // share of edges that go through the exchange buffer
+  int wavesPerSimd = 0;           // 8: the kernel is compiled for 64 registers per thread, so that TWO work-groups of 1024 threads share a
+                                  // CU (small row programs: they leave half the registers and more than half the LDS of a CU unused); 0: no limit
   long exchangeCells() const { return (long)G * nGRows * T; }   // cells of one exchange array
   long exchangeStride() const { return 3 * exchangeCells() + 2 * ((G + 15) & ~15); }   // doubles per cluster: XA.dc | XB.dc | XB.sc | reduction cells (viterbi_tiera.hip kXStride)
 };

@@ -458,7 +458,11 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
       } else {
         try {
           std::string defs = m->plan.defines;
-          if (const char* extra = getenv("DNAS_TIERA_DEFS")) defs += std::string("\n") + extra;   // diagnostics, e.g. -DDNAS_STAMP
+          if (const char* extra = getenv("DNAS_TIERA_DEFS")) {      // diagnostics, e.g. -DDNAS_STAMP; several: separated by ':', ' ' or newlines
+            std::string more = extra;
+            for (char& c : more) if (c == ':' || c == ' ') c = '\n';
+            defs += "\n" + more;
+          }
           m->jitDefs = defs;
           const std::vector<char> code = dnas::jitCompile(defs, m->plan.key);
           if (hipModuleLoadData(&m->module, code.data()) != hipSuccess ||
@@ -555,6 +559,14 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 1) {
       const int xcds = std::max(1, cus / 32);
       m->maxSlots = std::max(1, 3 * (cus - 2 * xcds));
+      // A small row program is compiled so that two work-groups share a CU (plan.cpp, wavesPerSimd): what the device says it holds
+      // of this kernel decides, and a launch is then ONE round of two reads per CU (measured on water64.1*l4c4, ~1050-nt reads:
+      // 480 reads per launch 0.565 of the roofline, 448: 0.53, 512: 0.51; one work-group per CU, 695 per launch: 0.41)
+      int perCu = 1;
+      if (m->plan.wavesPerSimd && hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, m->fillA, m->plan.T, m->plan.ldsBytes) == hipSuccess && perCu >= 2) {
+        m->maxSlots = std::max(1, 2 * (cus - 2 * xcds));
+        m->tierNote += "; 2 work-groups per CU";
+      }
     }
   }
   if (m->tier == 2) m->maxSlots = 1 << 20;   // persistent clusters walk any number of reads: a launch is bounded by the arena only
@@ -995,13 +1007,14 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
     m->sync.push_back(e);
   }
   if (m->tier == 2) {
-    m->syncCheckWords = (nBatches + cp.groupLaunches) * (size_t)m->maxClusters * 64;
-    if (m->syncCheckWords > m->syncCheckCap) {
+    const size_t wantWords = (nBatches + cp.groupLaunches) * (size_t)m->maxClusters * 64;
+    if (wantWords > m->syncCheckCap) {
       if (m->syncCheck) (void)hipHostFree(m->syncCheck);
-      m->syncCheck = nullptr; m->syncCheckCap = 0;
-      HIP_TRY(hipHostMalloc((void**)&m->syncCheck, m->syncCheckWords * sizeof(unsigned), hipHostMallocDefault));   // pinned: the copies after each fill stay asynchronous
-      m->syncCheckCap = m->syncCheckWords;
+      m->syncCheck = nullptr; m->syncCheckCap = 0; m->syncCheckWords = 0;
+      HIP_TRY(hipHostMalloc((void**)&m->syncCheck, wantWords * sizeof(unsigned), hipHostMallocDefault));   // pinned: the copies after each fill stay asynchronous
+      m->syncCheckCap = wantWords;
     }
+    m->syncCheckWords = wantWords;
     memset(m->syncCheck, 0, m->syncCheckWords * sizeof(unsigned));
     m->syncLaunches = nBatches + cp.groupLaunches;
   }
@@ -1175,9 +1188,10 @@ extern "C" int dnas_tiera_precompile(const dnas_flat_model* fm, char* note, size
     // the row program a model of this machine will run: as the environment says, else as its tuning record says, else the
     // default one
     dnas::PlanChoice choice;
+    const int threads = getenv("DNAS_THREADS") && atoi(getenv("DNAS_THREADS")) > 0 ? atoi(getenv("DNAS_THREADS")) : dnas::kTierAThreads;   // as dnas_model_create_ex reads it
     if (!getenv("DNAS_PLAN_ORDER") && !getenv("DNAS_PLAN_SLACK") && !(getenv("DNAS_RECORDS") && atoi(getenv("DNAS_RECORDS")) == 0))
-      (void)parse_plan_record(dnas::cacheNoteRead(tune_record_name(fm, 1, dnas::kTierAThreads)), &choice);
-    const dnas::TierAPlan p = dnas::buildTierAPlan(*fm, dnas::kTierAThreads, choice);
+      (void)parse_plan_record(dnas::cacheNoteRead(tune_record_name(fm, 1, threads)), &choice);
+    const dnas::TierAPlan p = dnas::buildTierAPlan(*fm, threads, choice);
     std::string msg;
     if (!p.ok) {
       msg = "tier B: " + p.whyNot;
@@ -1226,9 +1240,10 @@ extern "C" int dnas_tierc_precompile(const dnas_flat_model* fm, int32_t members,
   if (!fm) return dnas::fail(DNAS_E_INVALID, "null argument");
   try {
     dnas::PlanChoice choice;      // as a model of this machine will be planned: the environment, else its tuning record
+    const int threads = getenv("DNAS_THREADS") ? atoi(getenv("DNAS_THREADS")) : 0;   // (the same thread count names the record and shapes the plan)
     if (!getenv("DNAS_PLAN_ORDER") && !getenv("DNAS_PLAN_SLACK") && !(getenv("DNAS_RECORDS") && atoi(getenv("DNAS_RECORDS")) == 0))
-      (void)parse_plan_record(dnas::cacheNoteRead(tune_record_name(fm, members >= 2 ? members : 0, 0)), &choice);
-    const dnas::TierAPlan p = dnas::chooseClusterPlan(*fm, members, getenv("DNAS_THREADS") ? atoi(getenv("DNAS_THREADS")) : 0, choice);
+      (void)parse_plan_record(dnas::cacheNoteRead(tune_record_name(fm, members >= 2 ? members : 0, threads)), &choice);
+    const dnas::TierAPlan p = dnas::chooseClusterPlan(*fm, members, threads, choice);
     if (!p.ok) return dnas::fail(DNAS_E_UNSUPPORTED, p.whyNot);
     (void)dnas::jitCompile(p.defines, p.key);
     const std::string msg = "tier C: G=" + std::to_string(p.G) + " K=" + std::to_string(p.K) + " inbox rows " + std::to_string(p.nGRows) +

@@ -228,7 +228,14 @@ constexpr bool kEarlyOffers = DNAS_G == 1;   // one work-group per read: a colum
 constexpr unsigned kCells = (unsigned)DNAS_G * DNAS_GROWS * DNAS_T;
 constexpr unsigned kXStride = 3u * kCells + 2u * ((unsigned)DNAS_G + 15u & ~15u);   // doubles per cluster (kCells is a multiple of 64: every array starts a 128-byte line)
 
-extern "C" __global__ void __launch_bounds__(DNAS_T)
+// DNAS_WAVES_PER_EU (optional, the planner's choice for small row programs): the register budget that lets this many waves share
+// a SIMD, i.e. TWO work-groups of 1024 threads share a CU at 8
+#ifdef DNAS_WAVES_PER_EU
+#define DNAS_OCCUPANCY __attribute__((amdgpu_waves_per_eu(DNAS_WAVES_PER_EU, DNAS_WAVES_PER_EU)))
+#else
+#define DNAS_OCCUPANCY
+#endif
+extern "C" __global__ void __launch_bounds__(DNAS_T) DNAS_OCCUPANCY
 viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kEntries][T]
                    const unsigned* __restrict__ metaTab,                // [G][K][T]: mdl | ctx<<4 | flags
                    const unsigned char* __restrict__ bases, const unsigned long long* __restrict__ readOff,
