@@ -206,6 +206,14 @@ class Ctx:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (no CPU fallback)")
 
+    def describe(self, per_rank):
+        """What the process group really was (a scaling record must show that RCCL saw N ranks)."""
+        d = {"world_size": self.world, "backend": None, "per_rank": per_rank, "devices_visible": self.torch.cuda.device_count()}
+        if self.world > 1:
+            d["backend"] = self.dist.get_backend()
+            d["world_size"] = self.dist.get_world_size()
+        return d
+
     def fence(self):
         self.torch.cuda.synchronize()
         if self.world > 1:
@@ -283,11 +291,18 @@ def viterbi_line(ctx, config, variant, n_reads, steps, warmup, cpu_seconds, time
     ctx.fence()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed, float(shard_nt)], dtype=torch.float64, device=coll_device)
+    per_rank = [{"rank": 0, "value": shard_nt * steps / elapsed, "seconds": elapsed, "nt": shard_nt, "fill_ms": fill_ms}]
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        # every rank's own clock and shard, so that a scaling record shows what each of the N ranks did (all_gather: RCCL)
+        mine = torch.tensor([elapsed, float(shard_nt), fill_ms], dtype=torch.float64, device=coll_device)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [{"rank": r, "value": float(e[1]) * steps / float(e[0]), "seconds": float(e[0]), "nt": int(e[1]), "fill_ms": float(e[2])}
+                    for r, e in enumerate(every)]
         elapsed, total_nt = float(tmax[0]), float(tsum[1])
     else:
         total_nt = float(shard_nt)
@@ -378,6 +393,7 @@ def viterbi_line(ctx, config, variant, n_reads, steps, warmup, cpu_seconds, time
                          "rounds_per_column": stats["rounds"] / max(stats["columns"], 1),
                          "traceback_ms_per_step": tb_ms / steps},
             "cpu_baseline": cpu,
+            "distributed": ctx.describe(per_rank),
         }
         line.update(extra)
     dec.close()
@@ -406,6 +422,7 @@ def main():
     args = ap.parse_args()
 
     ctx = Ctx(args.gpus)
+    failed = []
     if args.config == 4:
         import bench_fwdback
         line = bench_fwdback.fwdback_line(ctx, args.reads, args.steps, args.warmup, args.cpu_seconds, args.timed_only)
@@ -427,14 +444,18 @@ def main():
             try:
                 o = fn()
                 o["bench_seconds"] = time.perf_counter() - t1
-            except (Exception, SystemExit) as e:       # a failure here is reported, the headline line still goes out
+            except (Exception, SystemExit) as e:       # a failure here is reported, the headline line still goes out -- and the run fails
                 o = {"error": "%s: %s" % (type(e).__name__, e)}
+                failed.append(name)
             others[name] = o
         line["other_configs"] = others
         line["other_configs_seconds"] = time.perf_counter() - t_all
+        line["other_configs_failed"] = failed
     if ctx.rank == 0:
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     ctx.close()
+    if failed:      # a parity failure or a crash in any configuration must not look like a successful run
+        raise SystemExit("bench.py: %s failed (see other_configs[...].error in the line above)" % ", ".join(failed))
 
 
 if __name__ == "__main__":

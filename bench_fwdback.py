@@ -77,9 +77,13 @@ def fwdback_line(ctx, n_pairs, steps, warmup, cpu_seconds, timed_only):
     fence()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed, float(nt), float(n_pairs)], dtype=torch.float64, device=coll_device)
+    elapsed_rank, per_rank = elapsed, None
     if world > 1:
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        per_rank = [{"rank": r, "value": float(e[1]) * steps / float(e[0]), "seconds": float(e[0]), "nt": int(e[1])} for r, e in enumerate(every)]
         elapsed, total_nt, total_pairs = float(tmax[0]), float(tsum[1]), float(tsum[2])
     else:
         total_nt, total_pairs = float(nt), float(n_pairs)
@@ -149,6 +153,18 @@ def fwdback_line(ctx, n_pairs, steps, warmup, cpu_seconds, timed_only):
                      "valu_active_share_of_wave_cycles": sq["derived"].get("valu_issue_share_of_wave_cycles")}
         except (OSError, ValueError, KeyError):
             pass
+        # HBM traffic of the E-step kernels: a recorded per-pair figure of separate rocprofv3 --pmc passes of this command (never
+        # measured in the bench run), newest round first; null when no profile exists
+        traffic, traffic_source = None, None
+        for rnd in ("r4", "r3"):
+            try:
+                src = os.path.join("profiles", "%s_traffic_config4.json" % rnd)
+                tj = json.load(open(os.path.join(ROOT, src)))
+                traffic = tj["hbm_bytes_per_pair_corrected"] * total_pairs / max(world, 1)
+                traffic_source = "%s (FETCH_SIZE x 2 + WRITE_SIZE per pair, separate rocprofv3 --pmc passes, scaled to this run's pairs per launch)" % src
+                break
+            except (OSError, ValueError, KeyError):
+                pass
         line = {
             "metric": "forward-backward E-step, read nt/sec (whole node)",
             "value": value, "unit": "nt/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -159,7 +175,7 @@ def fwdback_line(ctx, n_pairs, steps, warmup, cpu_seconds, timed_only):
                        "pairs_per_gpu": n_pairs, "total_nt": int(total_nt), "parallelism": "pair-sharded x%d, counts all-reduced" % world},
             "pairs_per_s": total_pairs * steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": alg_bytes * steps / (kernel_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg_bytes * steps / (kernel_ms / 1e3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
+                         "frac": alg_bytes * steps / (kernel_ms / 1e3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "fwdback_onchip16p6_kernel", "avg_launch_ms": kernel_ms / steps,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "the algorithmic bytes are inputs and outputs only, so this fraction says nothing: the kernel is bound by the "
@@ -169,6 +185,7 @@ def fwdback_line(ctx, n_pairs, steps, warmup, cpu_seconds, timed_only):
                          "lse_ops_per_s": lse_ops / (kernel_ms / 1e3) if kernel_ms > 0 else 0.0,
                          "pairs_onchip": st["pairs_onchip"], "pairs_streaming": st["pairs_streaming"]},
             "cpu_baseline": cpu,
+            "distributed": ctx.describe([{"rank": 0, "value": nt * steps / elapsed_rank, "seconds": elapsed_rank, "nt": nt}] if per_rank is None else per_rank),
         }
         line.update(extra)
     fb.close()

@@ -847,50 +847,59 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
       }
       int xh[D_ > 0 ? D_ : 1];   // xh[i] = x_{pos-i}
       static_for<0, D_>([&](auto ic) { xh[ic.value] = pos - ic.value >= 1 ? seq[pos - ic.value - 1] : 0; });
-      // the two rows of a cell pair are neighbours in the lattice: 16-byte loads and stores
+      // The two rows of a cell pair are neighbours in the lattice (rows 2m, 2m+1; clusters: the plan's choice, DNAS_PAIRS): 16-byte
+      // loads and stores.  The history comes back in GROUPS of DNAS_CGROUP rows, DNAS_CDEPTH groups in flight: the loads of group
+      // g + DNAS_CDEPTH go out when group g has been turned into its hand-over, so that only the first group's latency is
+      // waited for in full (all waves of a work-group are here at the same time: nothing else hides it).
+      // Measured (profiles/experiments/r4_ab_runs.txt): one work-group per read 4 rows x 1 group (0.640; 2 x 2: 0.632, 2 x 3: 0.624 --
+      // a CU's memory path, not the latency of one group, bounds the phase), clusters 2 rows x 3 groups (0.260 against 0.253).
 #ifndef DNAS_CGROUP
-#define DNAS_CGROUP 4
+#define DNAS_CGROUP (DNAS_G > 1 ? 2 : 4)
 #endif
-      if constexpr (G_ > 1) {
-      // clusters: the rows of a cell pair are the plan's choice (DNAS_PAIRS), and a thread without a state in a pair loads nothing
+#ifndef DNAS_CDEPTH
+#define DNAS_CDEPTH (DNAS_G > 1 ? 3 : 1)
+#endif
+      {
       constexpr int GP = DNAS_CGROUP / 2;          // cell pairs per load group
-      static_assert(GP >= 1, "a load group is at least one pair");
-      static_for<0, (K / 2 + GP - 1) / GP>([&](auto gc) {
+      static_assert(GP >= 1 && DNAS_CDEPTH >= 1, "a load group is at least one pair");
+      constexpr int NG = (K / 2 + GP - 1) / GP, PD = DNAS_CDEPTH < NG ? DNAS_CDEPTH : NG;
+      unsigned metaBuf[PD][2 * GP];                // a ring of PD groups: group g lives in slot g % PD
+      double shBuf[PD][2 * GP][D_ > 1 ? D_ - 1 : 1];
+      auto issueGroup = [&](auto gc) __attribute__((always_inline)) {
         constexpr int p0 = gc.value * GP, p1 = (p0 + GP < K / 2) ? p0 + GP : K / 2;
-        unsigned metaG[2 * GP];
         static_for<2 * p0, 2 * p1>([&](auto qc) {   // (address rebuilt here: 14 hoisted pointers would cost 28 registers)
           constexpr int k = kPairRows[qc.value];
-          metaG[qc.value - 2 * p0] = rowLive(k) ? META(k) : 0u;
+          metaBuf[gc.value % PD][qc.value - 2 * p0] = rowLive(k) ? META(k) : 0u;
         });
-        double sh[2 * GP][D_ > 1 ? D_ - 1 : 1];
         // clusters: a thread without a state in a pair is switched off by its offset (it reads 0, which nobody uses, and moves no
-        // bytes) -- formed here, from an opaque copy of the mask, so that the fourteen offsets are not kept in registers
-        {
-          const unsigned pv = opaque(pairValid);
+        // bytes) -- formed here, from an opaque copy of the mask, so that the fourteen offsets are not kept in registers; one
+        // work-group per read: every thread loads (switching threads off costs more than the bytes)
+        const unsigned pv = G_ > 1 ? opaque(pairValid) : ~0u;
+        static_for<1, D_>([&](auto ic) {
+          constexpr int i = ic.value;
+          // (in the first columns of a read the history is shorter than D - 1: nobody
+          //  uses what they bring (column pos - i < 1 does not exist: they fetch column pos instead) -- unconditional, so that a slot of the ring is dead from its last use to its next load)
+          const int colH = pos - i >= 1 ? pos - i : pos;
           static_for<p0, p1>([&](auto mc) {
             constexpr int m2 = mc.value;
             if constexpr (!rowLive(pairRow(m2, 0)) && !rowLive(pairRow(m2, 1))) return;
-            const unsigned off = (pv & (1u << m2)) ? tid16 : kLaneOff;
-            static_for<1, D_>([&](auto ic) {
-              constexpr int i = ic.value;
-              if (pos - i >= 1) {
-                // the oldest column is read for the last time: stream it past the caches
-                const dbl2 v2 = __builtin_bit_cast(dbl2, __builtin_amdgcn_raw_buffer_load_b128(COL_RSRC(pos - i), (int)off, (int)PAIR_OFF(0, m2),
-                                                                                                (DNAS_NT_H && i >= D_ - DNAS_NT_H) ? kAuxNt : 0));
-                sh[2 * (m2 - p0)][i - 1] = v2.x;
-                sh[2 * (m2 - p0) + 1][i - 1] = v2.y;
-              }
-            });
+            const unsigned off = (G_ == 1 || (pv & (1u << m2))) ? tid16 : kLaneOff;
+            // the oldest column is read for the last time: stream it past the caches
+            const dbl2 v2 = __builtin_bit_cast(dbl2, __builtin_amdgcn_raw_buffer_load_b128(COL_RSRC(colH), (int)off, (int)PAIR_OFF(0, m2),
+                                                                                            (DNAS_NT_H && i >= D_ - DNAS_NT_H) ? kAuxNt : 0));
+            shBuf[gc.value % PD][2 * (m2 - p0)][i - 1] = v2.x;
+            shBuf[gc.value % PD][2 * (m2 - p0) + 1][i - 1] = v2.y;
           });
-        }
-        if constexpr (kEarlyOffers && gc.value == 0) {
-          if (earlyOffered) emitOffers(xn);       // column pos + 1: ((S(pos) + score) + noGap) + sub[base][x_{pos+1}]
-        }
+        });
+      };
+      auto computeGroup = [&](auto gc) __attribute__((always_inline)) {
+        constexpr int p0 = gc.value * GP, p1 = (p0 + GP < K / 2) ? p0 + GP : K / 2;
         static_for<2 * p0, 2 * p1>([&](auto qc) {
-          constexpr int k = kPairRows[qc.value], q = qc.value - 2 * p0;
+          constexpr int k = kPairRows[qc.value], q = qc.value - 2 * p0, b = gc.value % PD;
           if constexpr (!rowLive(k)) { Dv[k] = kNegInf; return; }
           const double s = S[k];
-          const int mdl = (int)(metaG[q] & 15u);
+          const unsigned mt = metaBuf[b][q];
+          const int mdl = (int)(mt & 15u);
           if constexpr (!kEarlyOffers) {
             ldsWrite(DC_OWN(k), kNegInf);
             if constexpr (kRows[k].sIdx >= 0) ldsWrite(SC_OWN(k), kNegInf);
@@ -898,18 +907,18 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
           // T1(pos): chain from the deepest element (i = D-1) to i = 0.  Nearly every state has a
           // full context (mdl == D) and nearly every column a full history: that case is straight
           // line code, chosen per wave.
-          const bool valid = (metaG[q] & 0x20000000u) != 0;
+          const bool valid = (mt & 0x20000000u) != 0;
           double v = kNegInf;
           if (pos >= D_ && __all(mdl == D_ || !valid)) {
             if constexpr (D_ > 0) {
               double sd = s;
-              if constexpr (D_ > 1) sd = sh[q][D_ - 2];
+              if constexpr (D_ > 1) sd = shBuf[b][q][D_ - 2];
               v = (sd + a.tanDup) + a.len[D_ - 1];
               static_for<1, D_>([&](auto jc) {
                 constexpr int i = D_ - 1 - jc.value;         // i = D-2 .. 0
                 double sp = s;
-                if constexpr (i > 0) sp = sh[q][i - 1];
-                v = dmax(v + ldsRead(kTabBase + 32 + ((metaG[q] >> (4 + 2 * (i + 1))) & 3u) * 32 + xh[i] * 8),
+                if constexpr (i > 0) sp = shBuf[b][q][i - 1];
+                v = dmax(v + ldsRead(kTabBase + 32 + ((mt >> (4 + 2 * (i + 1))) & 3u) * 32 + xh[i] * 8),
                          (sp + a.tanDup) + a.len[i]);
               });
             }
@@ -918,90 +927,26 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
               constexpr int i = D_ - 1 - jc.value;           // lane q = i at column p = pos - i
               if (i < mdl && pos - i >= 1) {
                 double sp = s;
-                if constexpr (i > 0) sp = sh[q][i - 1];
+                if constexpr (i > 0) sp = shBuf[b][q][i - 1];
                 const double base = (sp + a.tanDup) + a.len[i];
                 if (i + 1 < mdl && pos - i - 1 >= 1)
-                  v = dmax(v + subL[((metaG[q] >> (4 + 2 * (i + 1))) & 3u) * 4 + xh[i]], base);
+                  v = dmax(v + subL[((mt >> (4 + 2 * (i + 1))) & 3u) * 4 + xh[i]], base);
                 else
                   v = base;
               }
             });
           }
           // next column: S >= T1(pos) + sub[ctx1][x_{pos+1}]   (viterbi.cpp:101-103)
-          Dv[k] = (valid && mdl > 0) ? v + subL[((metaG[q] >> 4) & 3u) * 4 + xn] : kNegInf;   // D(pos) is already on its way to HBM
+          Dv[k] = (valid && mdl > 0) ? v + subL[((mt >> 4) & 3u) * 4 + xn] : kNegInf;   // D(pos) is already on its way to HBM
         });
-      });
-      } else {
-      // one work-group per read: rows 2m, 2m+1 are the pairs, every thread loads (switching threads off costs more than the bytes)
-      constexpr int G = DNAS_CGROUP;               // rows per load group (even: whole pairs)
-      static_for<0, (K + G - 1) / G>([&](auto gc) {
-        constexpr int k0 = gc.value * G, k1 = (k0 + G < K) ? k0 + G : K;
-        unsigned metaG[G];
-        static_for<k0, k1>([&](auto kc) {   // (address rebuilt here: 14 hoisted pointers would cost 28 registers)
-          metaG[kc.value - k0] = rowLive(kc.value) ? META(kc.value) : 0u;
-        });
-        double sh[G][D_ > 1 ? D_ - 1 : 1];
-        static_for<1, D_>([&](auto ic) {
-          constexpr int i = ic.value;
-          if (pos - i >= 1) {
-            static_for<k0 / 2, k1 / 2>([&](auto mc) {
-              constexpr int m2 = mc.value;
-              if constexpr (!rowLive(2 * m2) && !rowLive(2 * m2 + 1)) return;
-              // the oldest column is read for the last time: stream it past the caches
-              const dbl2 v2 = __builtin_bit_cast(dbl2, __builtin_amdgcn_raw_buffer_load_b128(COL_RSRC(pos - i), (int)tid16, (int)PAIR_OFF(0, m2),
-                                                                                              (DNAS_NT_H && i >= D_ - DNAS_NT_H) ? kAuxNt : 0));
-              sh[2 * m2 - k0][i - 1] = v2.x;
-              sh[2 * m2 + 1 - k0][i - 1] = v2.y;
-            });
-          }
-        });
-        if constexpr (kEarlyOffers && gc.value == 0) {
-          if (earlyOffered) emitOffers(xn);       // column pos + 1: ((S(pos) + score) + noGap) + sub[base][x_{pos+1}]
-        }
-        static_for<k0, k1>([&](auto kc) {
-          constexpr int k = kc.value;
-          if constexpr (!rowLive(k)) { Dv[k] = kNegInf; return; }
-          const double s = S[k];
-          const int mdl = (int)(metaG[k - k0] & 15u);
-          if constexpr (!kEarlyOffers) {
-            ldsWrite(DC_OWN(k), kNegInf);
-            if constexpr (kRows[k].sIdx >= 0) ldsWrite(SC_OWN(k), kNegInf);
-          }
-          // T1(pos): chain from the deepest element (i = D-1) to i = 0.  Nearly every state has a
-          // full context (mdl == D) and nearly every column a full history: that case is straight
-          // line code, chosen per wave.
-          const bool valid = (metaG[k - k0] & 0x20000000u) != 0;
-          double v = kNegInf;
-          if (pos >= D_ && __all(mdl == D_ || !valid)) {
-            if constexpr (D_ > 0) {
-              double sd = s;
-              if constexpr (D_ > 1) sd = sh[k - k0][D_ - 2];
-              v = (sd + a.tanDup) + a.len[D_ - 1];
-              static_for<1, D_>([&](auto jc) {
-                constexpr int i = D_ - 1 - jc.value;         // i = D-2 .. 0
-                double sp = s;
-                if constexpr (i > 0) sp = sh[k - k0][i - 1];
-                v = dmax(v + ldsRead(kTabBase + 32 + ((metaG[k - k0] >> (4 + 2 * (i + 1))) & 3u) * 32 + xh[i] * 8),
-                         (sp + a.tanDup) + a.len[i]);
-              });
-            }
-          } else {
-            static_for<0, D_>([&](auto jc) {
-              constexpr int i = D_ - 1 - jc.value;           // lane q = i at column p = pos - i
-              if (i < mdl && pos - i >= 1) {
-                double sp = s;
-                if constexpr (i > 0) sp = sh[k - k0][i - 1];
-                const double base = (sp + a.tanDup) + a.len[i];
-                if (i + 1 < mdl && pos - i - 1 >= 1)
-                  v = dmax(v + subL[((metaG[k - k0] >> (4 + 2 * (i + 1))) & 3u) * 4 + xh[i]], base);
-                else
-                  v = base;
-              }
-            });
-          }
-          // next column: S >= T1(pos) + sub[ctx1][x_{pos+1}]   (viterbi.cpp:101-103)
-          Dv[k] = (valid && mdl > 0) ? v + subL[((metaG[k - k0] >> 4) & 3u) * 4 + xn] : kNegInf;   // D(pos) is already on its way to HBM
-        });
+      };
+      static_for<0, PD>([&](auto gc) { issueGroup(gc); });
+      if constexpr (kEarlyOffers) {
+        if (earlyOffered) emitOffers(xn);       // column pos + 1: ((S(pos) + score) + noGap) + sub[base][x_{pos+1}]
+      }
+      static_for<0, NG>([&](auto gc) {
+        computeGroup(gc);
+        if constexpr (gc.value + PD < NG) issueGroup(IntC<gc.value + PD>{});
       });
       }
       // the S lane goes out last: a wave's memory operations return in order, so a store issued

@@ -41,3 +41,35 @@ def test_two_ranks_on_one_card_equal_one_rank(tmp_path):
     assert line2["value"] > 0 and line2["roofline"]["frac"] > 0 and "program" in line2["config"]
     d2, d1 = json.load(open(two)), json.load(open(one))
     assert len(d2) == 128 and d2 == d1          # decoded strings, fp64 log-likelihood bits and status of every read
+
+
+def test_two_ranks_over_rccl_when_two_gpus_are_there(tmp_path):
+    """The measured configuration itself: two ranks, two GPUs, the real `nccl` backend (= RCCL over xGMI), reads scattered from rank
+    0 and results gathered to it.  Needs two visible GPUs: skipped on a one-GPU box (the driver's scaling run is the first place
+    where RCCL sees more than one rank; this test is collected there)."""
+    import torch
+    if torch.cuda.device_count() < 2:          # (counting devices does not initialise the GPU)
+        pytest.skip("needs 2 GPUs (RCCL cannot put two ranks on one device)")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    env.pop("DNAS_BENCH_BACKEND", None)
+    common = ["--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--timed-only"]
+    for extra, tag in (([], "per-rank reads"), (["--scatter"], "scatter")):
+        two = str(tmp_path / ("two_%s.json" % tag.split()[0]))
+        line = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                     "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--reads", "64", "--dump-decoded", two] + common + extra,
+                    env, tmp_path, "2 ranks over nccl, " + tag)
+        d = line["distributed"]
+        assert d["backend"] == "nccl" and d["world_size"] == 2 and len(d["per_rank"]) == 2
+        assert all(r["value"] > 0 and r["nt"] > 0 for r in d["per_rank"])
+        assert line["n_gpus"] == 2 and line["value"] > 0
+    one = str(tmp_path / "one.json")
+    _run([sys.executable, "bench.py", "--gpus", "1", "--reads", "128", "--dump-decoded", one] + common, env, tmp_path, "1 rank")
+    d2, d1 = json.load(open(str(tmp_path / "two_per-rank.json"))), json.load(open(one))
+    assert len(d2) == 128 and d2 == d1          # what two GPUs decode together equals what one decodes alone
+
+
+def test_line_says_what_the_process_group_was(tmp_path):
+    line = _run([sys.executable, "bench.py", "--gpus", "1", "--reads", "64", "--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--timed-only"],
+                dict(os.environ), tmp_path, "1 rank")
+    d = line["distributed"]
+    assert d["world_size"] == 1 and d["backend"] is None and len(d["per_rank"]) == 1 and d["per_rank"][0]["value"] > 0
