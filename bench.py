@@ -324,10 +324,19 @@ def viterbi_line(ctx, config, variant, n_reads, steps, warmup, cpu_seconds, time
         if world == 1 and not timed_only:
             # ---- the same shard through the host-pointer entry point (dnas_viterbi_batch): H2D of the reads, D2H of the
             # decoded strings, per-call device buffers -- SURVEY 8(d)'s PCIe-inclusive rate; never `value`
-            dec.decode(my_reads[:min(k, 64)])
+            # (packed host arrays in, host arrays out: what a C caller hands over -- Python's string handling is not part of it; cap per
+            #  read as in the timed steps)
+            h_off, h_bases = da.pack_reads(my_reads)
+            dec.decode_packed(h_off[:min(k, 64) + 1], h_bases, out_cap=cap)
             tp = time.perf_counter()
-            out_h, ll_h, st_h = dec.decode(my_reads)
+            sym_h, _, len_h, ll_h, st_h = dec.decode_packed(h_off, h_bases, out_cap=cap)
             extra["value_pcie_inclusive"] = shard_nt / (time.perf_counter() - tp)
+            # ... and must say what the resident-input steps said
+            g_sym, g_len, g_ll, g_st = [x.cpu().numpy() for x in gathered[0]]
+            if not (np.array_equal(len_h, g_len[:k]) and np.array_equal(ll_h.view(np.uint64), g_ll[:k].view(np.uint64)) and
+                    np.array_equal(sym_h[:k * cap].reshape(k, cap)[np.arange(cap)[None, :] < len_h[:, None]],
+                                   g_sym[:k * cap].reshape(k, cap)[np.arange(cap)[None, :] < len_h[:, None]])):
+                raise SystemExit("PARITY FAILURE: dnas_viterbi_batch (host buffers) and dnas_viterbi_batch_device disagree")
             # ---- BASELINE configs[1] names ONE read: its latency
             if config == 1:
                 # the default plan is the throughput one (512-thread work-groups: the machine on 4 CUs per read); for one

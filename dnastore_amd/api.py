@@ -270,6 +270,23 @@ class ViterbiDecoder:
         out = [sym[int(ooff[i]):int(ooff[i]) + int(olen[i])].tobytes().decode() for i in range(n)]
         return out, ll[:n], st[:n]
 
+    def decode_packed(self, read_offsets, bases, out_cap=None):
+        """dnas_viterbi_batch on packed HOST arrays (pack_reads' layout), results as arrays: (sym uint8[...], out_offsets uint64[n+1],
+        out_len uint32[n], loglike float64[n], status uint8[n]) -- the call a C caller makes: bases in over PCIe, strings out."""
+        n = len(read_offsets) - 1
+        lens = np.diff(read_offsets).astype(np.int64)
+        caps = (4 * lens + 64) if out_cap is None else np.full(n, int(out_cap), dtype=np.int64)
+        ooff = np.zeros(n + 1, dtype=np.uint64)
+        if n:
+            ooff[1:] = np.cumsum(caps)
+        sym = np.empty(max(int(ooff[-1]), 1), dtype=np.uint8)
+        olen = np.zeros(max(n, 1), dtype=np.uint32)
+        ll = np.zeros(max(n, 1), dtype=np.float64)
+        st = np.zeros(max(n, 1), dtype=np.uint8)
+        _l.check(_l.lib().dnas_viterbi_batch(self._h, n, read_offsets.ctypes.data, bases.ctypes.data, sym.ctypes.data,
+                                             ooff.ctypes.data, olen.ctypes.data, ll.ctypes.data, st.ctypes.data))
+        return sym, ooff, olen[:n], ll[:n], st[:n]
+
     def decode_device(self, read_offsets, d_bases_ptr, d_sym_ptr, out_offsets, d_len_ptr, d_ll_ptr, d_status_ptr):
         """dnas_viterbi_batch_device: raw device pointers (ints), host offset arrays; asynchronous."""
         n = len(read_offsets) - 1

@@ -27,16 +27,33 @@ def _decode_row(da, machine, rate, reps=REPS):
     return [c[0] for c in cases], [c[1] for c in cases], [s.replace("^", "").replace("$", "") for s in out], ll, out
 
 
-def test_no_edits_up_to_a_substitution_rate_of_0_004():
-    """Rows 1-6 of the table: MeanEditsPerBit 0, StDev 0 -- every one of the 20 payloads comes back exactly."""
+def test_next_to_no_edits_up_to_a_substitution_rate_of_0_004():
+    """Rows 1-6 of the table: MeanEditsPerBit 0 over 20 x 8192 bits.  Without substitutions every payload comes back exactly.  With
+    them we do NOT find exactly zero: a single substitution sometimes has two equally likely explanations (two code words one
+    transition away from the read) and the Viterbi path takes the wrong one -- 0 to 4 edited bits per row of 163 840
+    (profiles/r4_len4_ham_subs.txt), where the table's own neighbouring rows (one edited bit at 0.0057, three at 0.008) suggest
+    0.3 to 1.5.  The bound is therefore five bits per row, and every read that came back with edits is decoded again by the ORACLE
+    and must come back the same: whatever is wrong with those payloads is the reference algorithm's own answer."""
     import dnastore_amd as da
-    machine = da.Machine.fromFile(os.path.join(REF_DATA, "h74l4c4.json"))
-    for row in TABLE[:6]:
+    from oracle import oracle as O
+    O.build()
+    path = os.path.join(REF_DATA, "h74l4c4.json")
+    machine, om = da.Machine.fromFile(path), O.Machine.from_file(path)
+    for n, row in enumerate(TABLE[:6]):
         assert row["MeanEditsPerBit"] == 0 and row["StDevEditsPerBit"] == 0
-        payloads, reads, decoded, _, _ = _decode_row(da, machine, row["SubProb"])
+        rate = row["SubProb"]
+        payloads, reads, decoded, ll, raw = _decode_row(da, machine, rate)
         assert all(12000 < len(r) < 15000 for r in reads)           # 8192 bits are ~13.5 kb
         wrong = [i for i, (p, d) in enumerate(zip(payloads, decoded)) if p != d]
-        assert not wrong, "substitution rate %g: repetitions %s came back with edits (the reference's table says none)" % (row["SubProb"], wrong)
+        if rate == 0:
+            assert not wrong, "reads without a single error came back with edits"
+        edits = sum(AT.edit_distance(payloads[i], decoded[i]) for i in wrong)
+        print("substitution rate %g: %d edited bits of %d (repetitions %s)" % (rate, edits, REPS * AT.BITS, wrong))
+        assert edits <= 5, "substitution rate %g: %d edited bits in repetitions %s" % (rate, edits, wrong)
+        orc = O.ViterbiOracle(om, O.MutatorParams.from_cli(sub=rate, dup=0.0, del_open=0.0, del_ext=0.2, global_=True, length=4))
+        for i in wrong[:2]:
+            s_ref, ll_ref = orc.decode(reads[i])
+            assert raw[i] == s_ref and float(ll[i]) == ll_ref, "substitution rate %g, repetition %d: the GPU's edits are not the oracle's" % (rate, i)
 
 
 def test_about_one_edit_per_thousand_bits_at_0_128():
@@ -53,6 +70,7 @@ def test_about_one_edit_per_thousand_bits_at_0_128():
     print("substitution rate 0.128: %.4g edits per bit (sd %.3g) against the table's %.4g (sd %.3g): %.2f standard errors apart"
           % (mean, sd, row["MeanEditsPerBit"], row["StDevEditsPerBit"], (mean - row["MeanEditsPerBit"]) / se))
     assert abs(mean - row["MeanEditsPerBit"]) <= 3 * row["StDevEditsPerBit"]
+    assert abs(mean - row["MeanEditsPerBit"]) <= 3 * se          # ... and, tighter, within three standard errors of the difference of the two means
     assert mean > 0          # at this rate the code does not correct everything
 
 
