@@ -176,14 +176,15 @@ def fwdback_line(ctx, n_pairs, steps, warmup, cpu_seconds, timed_only):
             "pairs_per_s": total_pairs * steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": alg_bytes * steps / (kernel_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg_bytes * steps / (kernel_ms / 1e3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": "fwdback_onchip16p6_kernel", "avg_launch_ms": kernel_ms / steps,
+                         "kernel": "fwdback_onchip8x16p6_kernel" if st.get("pairs_narrow", 0) * 2 > st["pairs_onchip"] else "fwdback_onchip16x16p6_kernel",
+                         "avg_launch_ms": kernel_ms / steps,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "the algorithmic bytes are inputs and outputs only, so this fraction says nothing: the kernel is bound by the "
                                  "instruction stream of a cell (log-sum-exp look-ups, fp64 exp) -- see `issue`; lse_ops_per_s is its rate of "
                                  "log-sum-exp operations",
                          "issue": issue,
                          "lse_ops_per_s": lse_ops / (kernel_ms / 1e3) if kernel_ms > 0 else 0.0,
-                         "pairs_onchip": st["pairs_onchip"], "pairs_streaming": st["pairs_streaming"]},
+                         "pairs_onchip": st["pairs_onchip"], "pairs_narrow": st.get("pairs_narrow", 0), "pairs_streaming": st["pairs_streaming"]},
             "cpu_baseline": cpu,
             "distributed": ctx.describe([{"rank": 0, "value": nt * steps / elapsed_rank, "seconds": elapsed_rank, "nt": nt}] if per_rank is None else per_rank),
         }

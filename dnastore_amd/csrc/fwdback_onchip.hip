@@ -2,11 +2,15 @@
 // matrices (reference src/fwdback.cpp:43-116) and the posterior counts (fwdback.cpp:154-188, fwdback.h:92-112).
 // (The file keeps its round-2 name: the first version held a block of the matrices in LDS.)
 //
-// W lanes work on one pair as a systolic wavefront (W = 16 or 32: the widest envelope row the kernel serves).  Lane l owns
-// the rows ip = l, l + W, l + 2W ...; at step a it computes the cell (ip, a - ip) if that lies in the row's envelope
-// [lo(ip), hi(ip)].  A cell needs (ip-1, op-1) and (ip-1, op) -- what the lane below it computed two steps and one step ago:
-// they come over by a lane shuffle, not through memory -- and (ip, op-1), its own previous step, kept in registers.  A row
-// is at most W cells wide, so a lane has left its row before its next one comes up.
+// W lanes work on one pair as a systolic wavefront.  Lane l owns the rows ip = l, l + W, l + 2W ...; at step a it computes the cell
+// (ip, a - ip) if that lies in the row's envelope [lo(ip), hi(ip)].  A cell needs (ip-1, op-1) and (ip-1, op) -- what the lane
+// below it computed two steps and one step ago: they come over by a lane shuffle, not through memory -- and (ip, op-1), its own
+// previous step, kept in registers.  A lane must have left its row before its next one comes up: row ip is worked on at the steps
+// ip + lo(ip) .. ip + hi(ip), row ip + W from step ip + W + lo(ip + W) on, so what is needed is hi(ip) - lo(ip + W) < W for every
+// row.  A row of at most W cells always meets that (round 3: W = 16 or 32 = the widest row served); but the rows of an alignment
+// run down a DIAGONAL -- lo(ip + W) is about lo(ip) + W --, so half as many lanes do (W = 8 for rows of up to RW = 16 cells, W = 16
+// for up to 32: the host checks the inequality per pair, fwdback_runtime.hip): a lane then works 13 steps of 16 instead of 13 of
+// 32, and a wave carries twice the pairs for the same instructions.
 //
 //   pass 1   Forward over all rows; every finished cell (S, D and the P duplication lanes) goes to the slot's scratch in HBM
 //            (330 KB for a 256-nt pair: bandwidth this chip has to spare -- 0.8 TB/s at 1.4 * 10^6 pairs/s -- bought for not
@@ -79,19 +83,22 @@ __device__ __forceinline__ double lse(fb_rsrc_t tab, double a, double b) {
   return mx + lse_unary(tab, mx - mn);
 }
 
-// One wave = 64 / W pairs.  pairList[i] = index of the pair in the database; slot scratch: fbOnchipSlotDoubles(W, maxInLen)
-// doubles per pair slot: the Forward cells of the pair, [row][W cells][S, D, T[0..7]].
-template <int W, int kMaxP>
+// One wave = 64 / W pairs.  pairList[i] = index of the pair in the database.  Scratch of a wave: the Forward cells of its pairs,
+// [S, D, T[0..7]][step][64 lanes] -- a cell is filed under the STEP it was computed in (a - first step of its pair) and the lane
+// that computed it, so every store and every load of a wave goes to consecutive addresses (round 3 filed it under (row, column):
+// 64 lanes, 64 cache lines per access); the Backward pass meets cell (ip, op) in the same step a = ip + op and the same lane, its
+// left neighbour one step earlier, the two cells of the row above one and two steps earlier in the lane below.
+// fbOnchipWaveDoubles(maxSteps) doubles per wave.
+template <int W, int RW, int kMaxP>
 __device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_t* __restrict__ inSeqs, const int64_t* __restrict__ inOff,
                                                     const int8_t* __restrict__ outSeqs, const int64_t* __restrict__ outOff,
                                                     const int32_t* __restrict__ cmIn, const int64_t* __restrict__ cmInOff,
                                                     const int32_t* __restrict__ cmOut, const int64_t* __restrict__ cmOutOff,
                                                     const double* __restrict__ lseTab, const int64_t* __restrict__ pairList, int64_t nList,
                                                     double* __restrict__ pairCounts, double* __restrict__ pairLL, int maxInLen,
-                                                    unsigned long long* __restrict__ lseOps, double* __restrict__ scratch) {
+                                                    unsigned long long* __restrict__ lseOps, double* __restrict__ scratch, int maxSteps) {
   extern __shared__ double fbLds[];
   constexpr int PPG = 64 / W;                                       // pairs per wave
-  constexpr int kCell = 10;                                         // doubles per Forward cell in the slot's scratch: S, D, T[0..7]
   const int g = threadIdx.x / W, l = threadIdx.x % W;
   const int P = a.P, Dm = a.maxDistance;
   // LDS of this pair
@@ -102,9 +109,11 @@ __device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_
   short* const LO = reinterpret_cast<short*>(LENS_ + 8);             // [maxInLen + 2]
   short* const HI = LO + (maxInLen + 2);
   // scratch of this slot: every Forward cell of the pair
-  double* const FW = scratch + ((size_t)blockIdx.x * PPG + g) * fbOnchipSlotDoubles(W, maxInLen);
-  if (l < 16) SUBS_[l] = a.sub[l];
-  if (l < kMaxP) LENS_[l] = a.len[l];
+  const size_t compStride = (size_t)maxSteps * 64;                   // doubles between two components of a cell
+  double* const FW = scratch + (size_t)blockIdx.x * fbOnchipWaveDoubles(maxSteps) + threadIdx.x;   // + (component * maxSteps + step) * 64
+  const int belowT = (int)threadIdx.x - l + (l + W - 1) % W;         // the lane that owns the row above this lane's row
+  for (int i = l; i < 16; i += W) SUBS_[i] = a.sub[i];
+  for (int i = l; i < kMaxP; i += W) LENS_[i] = a.len[i];
   unsigned long long nLse = 0;
   const fb_rsrc_t lseRsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(lseTab), 0, 100001 * 8, 0x00020000);
 #define LSE(x, y) (++nLse, lse(lseRsrc, (x), (y)))
@@ -127,7 +136,7 @@ __device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_
   // ---- the envelope of every row (alignpath.h:48-53): op in [lo, hi] <=> |cm(ip) - cm(op)| <= maxDistance; cm is
   // non-decreasing along both sequences, so lo and hi are two binary searches per row
   WAVE_SYNC();
-  if (l < 16) SUBC[l] = 0;
+  for (int i = l; i < 16; i += W) SUBC[i] = 0;
   for (int ip = l; ip <= I; ip += W) {
     const int lowKey = ci[ip] - Dm, highKey = ci[ip] + Dm;
     int x = 0, y = O + 1;
@@ -140,6 +149,7 @@ __device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_
   }
   WAVE_SYNC();
 
+  const int aStart = live ? LO[0] : 0;                             // the pair's first step
   double ll = kNegInf;
   double T[kMaxP];                                                 // duplication lanes of this lane's previous cell
   double leftS = kNegInf;                                          // (Backward: S of the previous cell of the row)
@@ -177,7 +187,7 @@ __device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_
   // two steps ago is this lane's (ip-1, op) and (ip-1, op-1): the steps are global (a = ip + op), every cell has its one step
   {
     int ip = l;                                                    // this lane's row
-    int aNow = live ? LO[0] : 0;                                   // global step = ip + op
+    int aNow = aStart;                                             // global step = ip + op
     const int aLast = live ? I + HI[I] : -1;
     double curS = kNegInf, curD = kNegInf, prevS = kNegInf;        // this lane's cell of the step before, S of the one before that
     for (; __any(live && aNow <= aLast) && aNow <= 2 * 65536; ++aNow) {
@@ -193,11 +203,11 @@ __device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_
           double s, d;
           forwardCell(ip, op, hasIns, dS, dIn, uS, uD, uIn, s, d);
           curS = s; curD = d;
-          double* cell = FW + ((size_t)ip * W + (op - lo)) * kCell;
+          double* cell = FW + (size_t)(aNow - aStart) * 64;
           cell[0] = s;
-          cell[1] = d;
+          cell[compStride] = d;
 #pragma unroll
-          for (int k = 0; k < kMaxP; ++k) if (k < P) cell[2 + k] = T[k];
+          for (int k = 0; k < kMaxP; ++k) if (k < P) cell[(size_t)(2 + k) * compStride] = T[k];
           if (ip == I && op == O) ll = s;                          // loglike = sCell(inLen, outLen), fwdback.cpp:76
           if (op == hi) ip += W;                                   // row done: on to this lane's next row
         } else if (op > hi) {
@@ -229,25 +239,24 @@ __device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_
         const int lo = LO[ip], hi = HI[ip];
         const int op = aNow - ip;
         if (op >= lo && op <= hi) {
-          const int j = op - lo;
           const int mdl = ip < P ? ip : P;
           const int nlo = ip < I ? LO[ip + 1] : 0, nhi = ip < I ? HI[ip + 1] : -1;
-          const int loUp = ip > 0 ? LO[ip - 1] : 0;
           // the Forward cells this cell's counts look at -- its own, the duplication lanes of the one to its left, two of the row
           // above -- are on their way while the Backward cell is computed
-          const double* fc = FW + ((size_t)ip * W + j) * kCell;    // Forward cell (ip, op): S, D, T[]; fc - kCell: (ip, op-1)
-          const double* upF = FW + (size_t)(ip > 0 ? ip - 1 : 0) * W * kCell;
+          const int t = aNow - aStart;                             // this cell's step: Forward cell (ip, op) sits at (t, this lane)
+          const double* fc = FW + (size_t)t * 64;
           double ft[kMaxP];
           const bool fIns = op - 1 >= lo;
           {
-            const double* tb = fc - (fIns ? kCell : 0) + 2;
+            const double* tb = fc - (fIns ? 64 : 0) + 2 * compStride;        // (ip, op-1): one step earlier, this lane
 #pragma unroll
-            for (int k = 0; k < kMaxP; ++k) ft[k] = (k < P && fIns) ? tb[k] : kNegInf;
+            for (int k = 0; k < kMaxP; ++k) ft[k] = (k < P && fIns) ? tb[(size_t)k * compStride] : kNegInf;
           }
           const bool upDg = ip > 0 && op > 0 && inRow(ip - 1, op - 1), upU = ip > 0 && inRow(ip - 1, op);
-          const double fUpDiagS = upDg ? upF[(size_t)(op - 1 - loUp) * kCell] : kNegInf;
-          const double fUpS = upU ? upF[(size_t)(op - loUp) * kCell] : kNegInf, fUpD = upU ? upF[(size_t)(op - loUp) * kCell + 1] : kNegInf;
-          const double fOwnS = fc[0], fOwnD = fc[1];
+          const double* upF = fc + (belowT - (int)threadIdx.x);              // the lane below, same step
+          const double fUpDiagS = upDg ? upF[-2 * 64] : kNegInf;             // (ip-1, op-1): two steps earlier
+          const double fUpS = upU ? upF[-64] : kNegInf, fUpD = upU ? upF[-64 + (long)compStride] : kNegInf;   // (ip-1, op): one step earlier
+          const double fOwnS = fc[0], fOwnD = fc[compStride];
 
           double s = (ip == I && op == O) ? 0. : kNegInf, d = kNegInf;
           const bool hasIns = op < O && ip > 0 && op + 1 <= hi;    // (ip, op+1) in range: T[] and leftS are that cell's
@@ -321,7 +330,7 @@ __device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_
 #pragma unroll
       for (int k = 0; k < kMaxP; ++k) if (k < P) pc[21 + k] = cl[k];
     }
-    if (l < 16) pc[5 + l] = SUBC[l];
+    for (int i = l; i < 16; i += W) pc[5 + i] = SUBC[i];
   }
   }   // pairs of this slot
   if (lseOps) {
@@ -339,17 +348,22 @@ __device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_
 #ifndef DNAS_FB_MIN_WAVES
 #define DNAS_FB_MIN_WAVES 3      // waves per SIMD the register allocation leaves room for: the cell lives in ~235 registers; at 168 it spills 68 of them, and 12 waves per CU still run 1.34 x faster than 8 without spills (the kernel waits on memory)
 #endif
-#define FB_KERNEL(name, W, MP)                                                                                                    \
+#define FB_KERNEL(name, W, RW, MP)                                                                                                \
   extern "C" __global__ void __launch_bounds__(64, DNAS_FB_MIN_WAVES)                                                             \
   name(FbArgs a, const int8_t* __restrict__ inSeqs, const int64_t* __restrict__ inOff, const int8_t* __restrict__ outSeqs,        \
        const int64_t* __restrict__ outOff, const int32_t* __restrict__ cmIn, const int64_t* __restrict__ cmInOff,                 \
        const int32_t* __restrict__ cmOut, const int64_t* __restrict__ cmOutOff, const double* __restrict__ lseTab,                \
        const int64_t* __restrict__ pairList, int64_t nList, double* __restrict__ pairCounts, double* __restrict__ pairLL,         \
-       int maxInLen, unsigned long long* __restrict__ lseOps, double* __restrict__ scratch) {                                     \
-    fwdback_onchip_body<W, MP>(a, inSeqs, inOff, outSeqs, outOff, cmIn, cmInOff, cmOut, cmOutOff, lseTab, pairList, nList, pairCounts, \
-                           pairLL, maxInLen, lseOps, scratch);                                                                    \
+       int maxInLen, unsigned long long* __restrict__ lseOps, double* __restrict__ scratch, int maxSteps) {                       \
+    fwdback_onchip_body<W, RW, MP>(a, inSeqs, inOff, outSeqs, outOff, cmIn, cmInOff, cmOut, cmOutOff, lseTab, pairList, nList, pairCounts, \
+                           pairLL, maxInLen, lseOps, scratch, maxSteps);                                                          \
   }
-FB_KERNEL(fwdback_onchip16_kernel, 16, 8)
-FB_KERNEL(fwdback_onchip32_kernel, 32, 8)
-FB_KERNEL(fwdback_onchip16p6_kernel, 16, 6)
-FB_KERNEL(fwdback_onchip32p6_kernel, 32, 6)
+// name: lanes per pair x cells per row served; p6: up to 6 duplication lengths (the CLI's default model) in registers
+FB_KERNEL(fwdback_onchip8x16_kernel, 8, 16, 8)
+FB_KERNEL(fwdback_onchip16x16_kernel, 16, 16, 8)
+FB_KERNEL(fwdback_onchip16x32_kernel, 16, 32, 8)
+FB_KERNEL(fwdback_onchip32x32_kernel, 32, 32, 8)
+FB_KERNEL(fwdback_onchip8x16p6_kernel, 8, 16, 6)
+FB_KERNEL(fwdback_onchip16x16p6_kernel, 16, 16, 6)
+FB_KERNEL(fwdback_onchip16x32p6_kernel, 16, 32, 6)
+FB_KERNEL(fwdback_onchip32x32p6_kernel, 32, 32, 6)

@@ -20,11 +20,16 @@ extern "C" __global__ void fwdback_estep_kernel(FbArgs, const int8_t*, const int
                                                 const int32_t*, const int64_t*, const int32_t*, const int64_t*,
                                                 const double*, double*, double*, double*, double*, int64_t, int, int64_t, const int64_t*);
 #define FB_ONCHIP_ARGS FbArgs, const int8_t*, const int64_t*, const int8_t*, const int64_t*, const int32_t*, const int64_t*, const int32_t*, \
-                       const int64_t*, const double*, const int64_t*, int64_t, double*, double*, int, unsigned long long*, double*
-extern "C" __global__ void fwdback_onchip16_kernel(FB_ONCHIP_ARGS);
-extern "C" __global__ void fwdback_onchip32_kernel(FB_ONCHIP_ARGS);
-extern "C" __global__ void fwdback_onchip16p6_kernel(FB_ONCHIP_ARGS);     // ... with up to 6 duplication lengths (the CLI's default model) in registers
-extern "C" __global__ void fwdback_onchip32p6_kernel(FB_ONCHIP_ARGS);
+                       const int64_t*, const double*, const int64_t*, int64_t, double*, double*, int, unsigned long long*, double*, int
+// <lanes per pair>x<cells per row served>; p6: up to 6 duplication lengths (the CLI's default model) in registers
+extern "C" __global__ void fwdback_onchip8x16_kernel(FB_ONCHIP_ARGS);
+extern "C" __global__ void fwdback_onchip16x16_kernel(FB_ONCHIP_ARGS);
+extern "C" __global__ void fwdback_onchip16x32_kernel(FB_ONCHIP_ARGS);
+extern "C" __global__ void fwdback_onchip32x32_kernel(FB_ONCHIP_ARGS);
+extern "C" __global__ void fwdback_onchip8x16p6_kernel(FB_ONCHIP_ARGS);
+extern "C" __global__ void fwdback_onchip16x16p6_kernel(FB_ONCHIP_ARGS);
+extern "C" __global__ void fwdback_onchip16x32p6_kernel(FB_ONCHIP_ARGS);
+extern "C" __global__ void fwdback_onchip32x32p6_kernel(FB_ONCHIP_ARGS);
 extern "C" __global__ void fwdback_reduce_kernel(const double*, const double*, int64_t, int, double*);
 
 #define HIP_TRY(expr)                                                                          \
@@ -57,6 +62,8 @@ const std::vector<double>& lseTable() {
 
 bool isTransition(int x, int y) { return x != y && (x & 1) == (y & 1); }
 
+constexpr int kFbLanes[4] = {8, 16, 16, 32}, kFbRowCells[4] = {16, 16, 32, 32};   // the four wavefront kernels
+
 }  // namespace
 
 // ---- the persistent handle ---------------------------------------------------------------------------
@@ -79,10 +86,11 @@ struct dnas_fb {
   int32_t *dCi = nullptr, *dCo = nullptr;
   double *dCounts = nullptr, *dLL = nullptr, *dPartial = nullptr;
   unsigned long long* dLseOps = nullptr;
-  // per guide mode (0: the envelope is maxDistance = P wide, 1: strict) and P: which kernel takes which pair
-  // (onchip[0]: envelope rows of at most 16 cells, 16 lanes per pair; onchip[1]: up to 32 cells, 32 lanes per pair)
-  struct Route { int P = -1; int maxInOnchip[2] = {0, 0}; std::vector<int64_t> onchip[2], streaming; std::vector<int64_t> cells; std::vector<int> width;
-                 int64_t* dOnchip[2] = {nullptr, nullptr}; int64_t* dStreaming = nullptr; };
+  // per guide mode (0: the envelope is maxDistance = P wide, 1: strict) and P: which kernel takes which pair.  onchip[q]: the
+  // wavefront kernels, kFbLanes[q] lanes per pair for envelope rows of up to kFbRowCells[q] cells; the narrow ones (q = 0, 2) take
+  // the pairs whose rows meet hi(ip) - lo(ip + W) < W (fwdback_onchip.hip), i.e. every alignment that runs down a diagonal
+  struct Route { int P = -1; int maxInOnchip[4] = {0, 0, 0, 0}, maxSteps[4] = {1, 1, 1, 1}; std::vector<int64_t> onchip[4], streaming; std::vector<int64_t> cells; std::vector<int> width;
+                 int64_t* dOnchip[4] = {nullptr, nullptr, nullptr, nullptr}; int64_t* dStreaming = nullptr; };
   Route route[2];
   // streaming kernel arenas
   double *dFwd = nullptr, *dRows = nullptr;
@@ -234,36 +242,55 @@ extern "C" int dnas_fb_estep(dnas_fb* h, const dnas_mutator_params* p, int stric
   if (rt.P != P) {
     for (int64_t*& q : rt.dOnchip) { if (q) (void)hipFree(q); q = nullptr; }
     if (rt.dStreaming) { (void)hipFree(rt.dStreaming); rt.dStreaming = nullptr; }
-    rt.onchip[0].clear(); rt.onchip[1].clear(); rt.streaming.clear();
+    for (auto& list : rt.onchip) list.clear();
+    rt.streaming.clear();
     rt.cells.assign((size_t)n_pairs, 1);
     rt.width.assign((size_t)n_pairs, 1);
     const int Dm = a.maxDistance;
     const bool forceStreaming = getenv("DNAS_FB_STREAMING") != nullptr;
     // the on-chip kernels keep a pair's envelope bounds in LDS: a pair whose input is too long for that goes to the streaming
     // kernel like the pairs with wider envelope rows (never fail the call for it)
-    int longest[2] = {0, 0};
-    for (int w = 0; w < 2; ++w)
-      while ((size_t)(kFbWave / (16 << w)) * fbOnchipPairDoubles(16 << w, longest[w] + 64) * sizeof(double) <= kFbOnchipLdsLimit) longest[w] += 64;
-    rt.maxInOnchip[0] = rt.maxInOnchip[1] = 0;
+    int longest[4] = {0, 0, 0, 0};
+    for (int q = 0; q < 4; ++q)
+      while ((size_t)(kFbWave / kFbLanes[q]) * fbOnchipPairDoubles(kFbLanes[q], longest[q] + 64) * sizeof(double) <= kFbOnchipLdsLimit) longest[q] += 64;
+    for (int& v : rt.maxInOnchip) v = 0;
+    for (int& v : rt.maxSteps) v = 1;
+    const bool noNarrow = getenv("DNAS_FB_NO_NARROW") != nullptr;       // (measurement: the round-3 routing, W = the row capacity)
+    std::vector<int> rowLo, rowHi;
     for (int64_t i = 0; i < n_pairs; ++i) {
       const int64_t inLen = h->inOff[i + 1] - h->inOff[i], outLen = h->outOff[i + 1] - h->outOff[i];
       const int32_t* ci = h->ci.data() + h->ciOff[i];
       const int32_t* co = h->co.data() + h->coOff[i];
       int64_t lo = 0, hi = -1, tot = 0;
       int w = 1;
+      rowLo.assign((size_t)inLen + 1, 0); rowHi.assign((size_t)inLen + 1, -1);
       for (int64_t ip = 0; ip <= inLen; ++ip) {
         while (lo <= outLen && co[lo] < ci[ip] - Dm) ++lo;
         if (hi < lo - 1) hi = lo - 1;
         while (hi + 1 <= outLen && co[hi + 1] <= ci[ip] + Dm) ++hi;
         tot += hi - lo + 1;
         w = std::max<int>(w, (int)(hi - lo + 1));
+        rowLo[(size_t)ip] = (int)lo; rowHi[(size_t)ip] = (int)hi;
       }
       rt.cells[(size_t)i] = std::max<int64_t>(tot, 1);
       rt.width[(size_t)i] = w;
-      const int kind = w <= 16 ? 0 : (w <= 32 ? 1 : 2);
-      const bool chip = kind < 2 && P <= 8 && inLen <= longest[kind] && outLen < 32000 && !forceStreaming;
+      int kind = w <= 16 ? 1 : (w <= 32 ? 3 : 4);            // the full-width kernel of the row capacity ...
+      if (kind < 4 && !noNarrow) {
+        // ... or half the lanes, when every lane has left its row before its next one comes up (Forward: rows ip, ip + W;
+        // Backward walks the same rows the other way: the same inequalities)
+        const int W = kFbLanes[kind - 1];
+        bool fits = true;
+        for (int64_t ip = 0; ip + W <= inLen && fits; ++ip)
+          fits = rowHi[(size_t)ip] < rowLo[(size_t)ip] /* empty row */ || rowHi[(size_t)ip] - rowLo[(size_t)(ip + W)] < W;
+        if (fits) --kind;
+      }
+      const bool chip = kind < 4 && P <= 8 && inLen <= longest[kind] && outLen < 32000 && !forceStreaming;
       (chip ? rt.onchip[kind] : rt.streaming).push_back(i);
-      if (chip) rt.maxInOnchip[kind] = std::max<int>(rt.maxInOnchip[kind], (int)inLen);
+      if (chip) {
+        rt.maxInOnchip[kind] = std::max<int>(rt.maxInOnchip[kind], (int)inLen);
+        // the steps of the pair's wavefront: a = ip + op from lo(0) to inLen + hi(inLen)
+        rt.maxSteps[kind] = std::max<int>(rt.maxSteps[kind], (int)inLen + std::max(rowHi[(size_t)inLen], 0) - rowLo[0] + 1);
+      }
     }
     // the pairs of a wave walk in step: neighbours in the list should be of a length (longest first)
     for (auto& list : rt.onchip)
@@ -273,8 +300,7 @@ extern "C" int dnas_fb_estep(dnas_fb* h, const dnas_mutator_params* p, int stric
       if (e == hipSuccess && !v.empty()) e = hipMemcpy(*d, v.data(), v.size() * sizeof(int64_t), hipMemcpyHostToDevice);
       return e;
     };
-    HIP_TRY(put(rt.onchip[0], &rt.dOnchip[0]));
-    HIP_TRY(put(rt.onchip[1], &rt.dOnchip[1]));
+    for (int q = 0; q < 4; ++q) HIP_TRY(put(rt.onchip[q], &rt.dOnchip[q]));
     HIP_TRY(put(rt.streaming, &rt.dStreaming));
     rt.P = P;
   }
@@ -288,33 +314,37 @@ extern "C" int dnas_fb_estep(dnas_fb* h, const dnas_mutator_params* p, int stric
   HIP_TRY(hipMemsetAsync(h->dLseOps, 0, sizeof(unsigned long long), h->stream));
   HIP_TRY(hipEventRecord(h->ev0, h->stream));
 
-  // ---- on-chip kernels: a wave per work-group (4 pairs of 16 lanes, or 2 of 32), persistent over the list
-  for (int w = 0; w < 2; ++w) {
+  // ---- on-chip kernels: a wave per work-group (8 pairs of 8 lanes, 4 of 16, or 2 of 32), persistent over the list
+  for (int w = 0; w < 4; ++w) {
     if (rt.onchip[w].empty()) continue;
-    const int W = 16 << w, ppg = kFbWave / W;
+    const int W = kFbLanes[w], RW = kFbRowCells[w], ppg = kFbWave / W;
     const size_t lds = (size_t)ppg * fbOnchipPairDoubles(W, rt.maxInOnchip[w]) * sizeof(double);   // <= kFbOnchipLdsLimit by the routing
     const int64_t nL = (int64_t)rt.onchip[w].size();
     // work-groups (= waves) a CU holds: 160 KB of LDS, and 16 waves of the kernel's 128 registers per lane
     const int perCu = std::max(1, std::min(DNAS_FB_WAVES_PER_CU, (int)((size_t)(160 * 1024) / lds)));
-    // every slot keeps the Forward cells of the pair it works on in HBM (330 KB for a 256-nt pair): the slots of a launch are
+    // every wave keeps the Forward cells of the pairs it works on in HBM (2.7 MB for 256-nt pairs): the waves of a launch are
     // bounded by a scratch budget (16 GB, a quarter of what is free) when the inputs are long
-    const size_t slotBytes = fbOnchipSlotDoubles(W, rt.maxInOnchip[w]) * sizeof(double);
+    (void)RW;
+    const size_t waveBytes = fbOnchipWaveDoubles(rt.maxSteps[w]) * sizeof(double);
     size_t freeB = 0, totalB = 0;
     HIP_TRY(hipMemGetInfo(&freeB, &totalB));
     const size_t budget = std::max<size_t>(h->scratchBytes, std::min<size_t>((size_t)16 << 30, (freeB + h->scratchBytes) / 4));
-    const int64_t slotsMax = std::max<int64_t>(1, (int64_t)(budget / ((size_t)ppg * slotBytes)));
+    const int64_t slotsMax = std::max<int64_t>(1, (int64_t)(budget / waveBytes));
     const unsigned grid = (unsigned)std::min<int64_t>(std::min<int64_t>((nL + ppg - 1) / ppg, (int64_t)h->cus * perCu), slotsMax);
-    const size_t need = (size_t)grid * ppg * slotBytes;
+    const size_t need = (size_t)grid * waveBytes;
     if (need > h->scratchBytes) {
       HIP_TRY(hipStreamSynchronize(h->stream));
       if (h->dScratch) { (void)hipFree(h->dScratch); h->dScratch = nullptr; h->scratchBytes = 0; }
       HIP_TRY(hipMalloc((void**)&h->dScratch, need));
       h->scratchBytes = need;
     }
-    auto kernel = P <= 6 ? (w == 0 ? fwdback_onchip16p6_kernel : fwdback_onchip32p6_kernel) : (w == 0 ? fwdback_onchip16_kernel : fwdback_onchip32_kernel);
+    void (*const kernels[2][4])(FB_ONCHIP_ARGS) = {
+        {fwdback_onchip8x16_kernel, fwdback_onchip16x16_kernel, fwdback_onchip16x32_kernel, fwdback_onchip32x32_kernel},
+        {fwdback_onchip8x16p6_kernel, fwdback_onchip16x16p6_kernel, fwdback_onchip16x32p6_kernel, fwdback_onchip32x32p6_kernel}};
+    auto kernel = kernels[P <= 6 ? 1 : 0][w];
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kFbWave), lds, h->stream, a, h->dIn, h->dInOff,
                        h->dOut, h->dOutOff, h->dCi, h->dCiOff, h->dCo, h->dCoOff, h->dTab, rt.dOnchip[w], nL, h->dCounts, h->dLL, rt.maxInOnchip[w],
-                       h->dLseOps, h->dScratch);
+                       h->dLseOps, h->dScratch, rt.maxSteps[w]);
     HIP_TRY(hipGetLastError());
   }
   // ---- streaming kernel for the rest: the interleaved Forward arena holds cellCap cells for each of B pairs
@@ -376,7 +406,8 @@ extern "C" int dnas_fb_estep(dnas_fb* h, const dnas_mutator_params* p, int stric
   float ms = 0;
   HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
   h->stats.kernel_ms = ms;
-  h->stats.pairs_onchip = (int64_t)(rt.onchip[0].size() + rt.onchip[1].size());
+  h->stats.pairs_onchip = (int64_t)(rt.onchip[0].size() + rt.onchip[1].size() + rt.onchip[2].size() + rt.onchip[3].size());
+  h->stats.pairs_narrow = (int64_t)(rt.onchip[0].size() + rt.onchip[2].size());
   h->stats.pairs_streaming = (int64_t)rt.streaming.size();
   h->stats.lse_ops = (int64_t)ops;
   int64_t ntOut = 0;

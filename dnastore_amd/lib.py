@@ -55,7 +55,7 @@ class PairsViewC(ctypes.Structure):
 
 class FbStatsC(ctypes.Structure):
     _fields_ = [("kernel_ms", ctypes.c_double), ("pairs_onchip", ctypes.c_int64), ("pairs_streaming", ctypes.c_int64),
-                ("lse_ops", ctypes.c_int64), ("out_nt", ctypes.c_int64)]
+                ("lse_ops", ctypes.c_int64), ("out_nt", ctypes.c_int64), ("pairs_narrow", ctypes.c_int64)]
 
 
 class BatchStatsC(ctypes.Structure):

@@ -254,8 +254,8 @@ int dnas_fwdback_estep(const dnas_mutator_params *params, int strict, int64_t n_
 
 /* The same E-step behind a persistent handle: the log-sum-exp table (per device) and the database (per load) go to
  * the GPU once; dnas_fb_estep then runs on the handle's own stream with buffers it keeps -- the EM loop calls it up
- * to 100 times.  Pairs whose envelope rows are at most 16 cells wide (and n_len <= 8) are served by the on-chip
- * kernel (nothing of the DP matrices touches HBM); the rest by the streaming kernel.  dnas_fwdback_estep and
+ * to 100 times.  Pairs whose envelope rows are at most 32 cells wide (and n_len <= 8) are served by the wavefront
+ * kernels (a group of 8, 16 or 32 lanes per pair, neighbours by lane shuffle); the rest by the streaming kernel.  dnas_fwdback_estep and
  * dnas_baum_welch are built on this. */
 typedef struct dnas_fb dnas_fb;
 typedef struct dnas_fb_stats {
@@ -263,6 +263,7 @@ typedef struct dnas_fb_stats {
   int64_t pairs_onchip, pairs_streaming;
   int64_t lse_ops;                  /* log_sum_exp evaluations of the on-chip kernel (counted in the kernel) */
   int64_t out_nt;                   /* sum of the read (output) lengths */
+  int64_t pairs_narrow;             /* ... of pairs_onchip: served with half as many lanes as the row capacity (alignments that run down a diagonal) */
 } dnas_fb_stats;
 int dnas_fb_create(int device_id, dnas_fb **out);
 int dnas_fb_load_pairs(dnas_fb *h, int64_t n_pairs, const int8_t *in_seqs, const int64_t *in_off, const int8_t *out_seqs,
