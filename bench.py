@@ -339,15 +339,17 @@ def viterbi_line(ctx, config, variant, n_reads, steps, warmup, cpu_seconds, time
                 raise SystemExit("PARITY FAILURE: dnas_viterbi_batch (host buffers) and dnas_viterbi_batch_device disagree")
             # ---- BASELINE configs[1] names ONE read: its latency
             if config == 1:
-                # the default plan is the throughput one (512-thread work-groups: the machine on 4 CUs per read); for one
-                # read alone 1024-thread work-groups (5 CUs per read, shorter sweeps) are the faster choice: "threads=1024"
-                dec_lat = da.ViterbiDecoder(machine, params, device=ctx.local_rank, options="threads=1024")
+                # the default plan is the throughput one (512-thread work-groups: the machine on 4 CUs per read); one read alone is
+                # decoded soonest on MORE, smaller members -- 16 work-groups of 512 threads, 8 rows per thread (measured, fill of
+                # one ~980-nt read: 43.9 ms; 5 x 1024 threads: 49.0; 8 x 512: 48.4; 16 x 1024: 71; 32 x 1024: 89-94:
+                # profiles/experiments/r4_single_read_latency.txt)
+                dec_lat = da.ViterbiDecoder(machine, params, device=ctx.local_rank, options="threads=512,cluster=16")
                 dec_lat.decode(my_reads[:1])
                 tp = time.perf_counter()
                 dec_lat.decode(my_reads[:1])
                 extra["latency_ms_single_read"] = (time.perf_counter() - tp) * 1e3
                 extra["fill_ms_single_read"] = dec_lat.stats()["fill_ms"]
-                extra["single_read_plan"] = dec_lat.tier[:40]
+                extra["single_read_plan"] = dec_lat.tier[:60]
                 dec_lat.close()
             # ---- parity spot check + CPU baseline (rank 0, N = 1 only), outside the timed region
             if cpu_seconds > 0:

@@ -70,7 +70,27 @@ std::string kernelCacheDir() {
 #endif
 
 unsigned long long textHash(const std::string& text) { return (unsigned long long)fnv1a(text + "|" DNAS_ARCH); }
-unsigned long long kernelSourceHash() { return (unsigned long long)fnv1a(tieraSource()); }
+// What a tuning record names as "kernel=": the hash of the kernel's CODE -- comments and white space taken out, so that a
+// reworded comment does not make the measured records stale (the code-object cache above keys on the full text).
+unsigned long long kernelSourceHash() {
+  const std::string src = tieraSource();
+  std::string code;
+  code.reserve(src.size());
+  for (size_t i = 0; i < src.size();) {
+    if (src.compare(i, 2, "//") == 0) { while (i < src.size() && src[i] != '\n') ++i; continue; }
+    if (src.compare(i, 2, "/*") == 0) { const size_t e = src.find("*/", i + 2); i = e == std::string::npos ? src.size() : e + 2; continue; }
+    if (src[i] == '"') {                      // (string literals stay as they are)
+      const size_t e = src.find('"', i + 1);
+      const size_t stop = e == std::string::npos ? src.size() : e + 1;
+      code.append(src, i, stop - i);
+      i = stop;
+      continue;
+    }
+    if (src[i] == ' ' || src[i] == '\t' || src[i] == '\n' || src[i] == '\r' || src[i] == '\\') { ++i; continue; }
+    code.push_back(src[i++]);
+  }
+  return (unsigned long long)fnv1a(code);
+}
 
 // looked for in the kernel cache first, then among the records shipped with the library (<library dir>/tune/: the verdicts
 // for the fixture and bench machines, regenerated with tools/make_tune_records.sh whenever the kernel source changes)

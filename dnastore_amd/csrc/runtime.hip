@@ -248,6 +248,17 @@ bool follow_plan_record(const dnas_flat_model* fm, int members, int threads, dna
   return true;
 }
 
+// The choice a model of this machine would be planned with when nothing is forced by an option: the environment (DNAS_PLAN_ORDER,
+// DNAS_PLAN_SLACK: left to the planner), else the machine's tuning record unless DNAS_RECORDS=0, else the default.  The
+// precompile and analysis entry points use it, so that what they compile or describe is the program a model runs.
+dnas::PlanChoice env_or_recorded_choice(const dnas_flat_model* fm, int members, int threads) {
+  dnas::PlanChoice choice;
+  if (!getenv("DNAS_PLAN_ORDER") && !getenv("DNAS_PLAN_SLACK") && !(getenv("DNAS_RECORDS") && atoi(getenv("DNAS_RECORDS")) == 0))
+    (void)parse_plan_record(dnas::cacheNoteRead(tune_record_name(fm, members, threads)), &choice);
+  return choice;
+}
+int env_threads(int fallback) { return getenv("DNAS_THREADS") && atoi(getenv("DNAS_THREADS")) > 0 ? atoi(getenv("DNAS_THREADS")) : fallback; }
+
 // autotune=1 and no record: time the candidate programs on synthetic reads once (one launch each), keep the verdict in the
 // kernel cache.  The reads are what a random walk through the machine emits (a code word sequence) with one base in a hundred
 // substituted; the lattice arena of the timing models is the caller's (at most 8 GiB).
@@ -1164,7 +1175,8 @@ extern "C" int dnas_tiera_plan_tables(const dnas_flat_model* fm, int32_t* row_sh
                                       uint32_t* meta, int32_t* n_entries, int32_t* n_s_rows) {
   if (!fm) return dnas::fail(DNAS_E_INVALID, "null argument");
   try {
-    const dnas::TierAPlan p = dnas::buildTierAPlan(*fm);
+    const int threads = env_threads(dnas::kTierAThreads);
+    const dnas::TierAPlan p = dnas::buildTierAPlan(*fm, threads, env_or_recorded_choice(fm, 1, threads));
     if (!p.ok) return dnas::fail(DNAS_E_UNSUPPORTED, p.whyNot);
     if (n_entries) *n_entries = p.nEntries;
     if (n_s_rows) *n_s_rows = p.nSRows;
@@ -1187,11 +1199,8 @@ extern "C" int dnas_tiera_precompile(const dnas_flat_model* fm, char* note, size
   try {
     // the row program a model of this machine will run: as the environment says, else as its tuning record says, else the
     // default one
-    dnas::PlanChoice choice;
-    const int threads = getenv("DNAS_THREADS") && atoi(getenv("DNAS_THREADS")) > 0 ? atoi(getenv("DNAS_THREADS")) : dnas::kTierAThreads;   // as dnas_model_create_ex reads it
-    if (!getenv("DNAS_PLAN_ORDER") && !getenv("DNAS_PLAN_SLACK") && !(getenv("DNAS_RECORDS") && atoi(getenv("DNAS_RECORDS")) == 0))
-      (void)parse_plan_record(dnas::cacheNoteRead(tune_record_name(fm, 1, threads)), &choice);
-    const dnas::TierAPlan p = dnas::buildTierAPlan(*fm, threads, choice);
+    const int threads = env_threads(dnas::kTierAThreads);   // as dnas_model_create_ex reads it
+    const dnas::TierAPlan p = dnas::buildTierAPlan(*fm, threads, env_or_recorded_choice(fm, 1, threads));
     std::string msg;
     if (!p.ok) {
       msg = "tier B: " + p.whyNot;
@@ -1239,11 +1248,8 @@ extern "C" int dnas_model_read_events(dnas_model* m, int64_t read_index, uint64_
 extern "C" int dnas_tierc_precompile(const dnas_flat_model* fm, int32_t members, char* note, size_t note_cap) {
   if (!fm) return dnas::fail(DNAS_E_INVALID, "null argument");
   try {
-    dnas::PlanChoice choice;      // as a model of this machine will be planned: the environment, else its tuning record
-    const int threads = getenv("DNAS_THREADS") ? atoi(getenv("DNAS_THREADS")) : 0;   // (the same thread count names the record and shapes the plan)
-    if (!getenv("DNAS_PLAN_ORDER") && !getenv("DNAS_PLAN_SLACK") && !(getenv("DNAS_RECORDS") && atoi(getenv("DNAS_RECORDS")) == 0))
-      (void)parse_plan_record(dnas::cacheNoteRead(tune_record_name(fm, members >= 2 ? members : 0, threads)), &choice);
-    const dnas::TierAPlan p = dnas::chooseClusterPlan(*fm, members, threads, choice);
+    const int threads = env_threads(0);   // (the same thread count names the record and shapes the plan)
+    const dnas::TierAPlan p = dnas::chooseClusterPlan(*fm, members, threads, env_or_recorded_choice(fm, members >= 2 ? members : 0, threads));
     if (!p.ok) return dnas::fail(DNAS_E_UNSUPPORTED, p.whyNot);
     (void)dnas::jitCompile(p.defines, p.key);
     const std::string msg = "tier C: G=" + std::to_string(p.G) + " K=" + std::to_string(p.K) + " inbox rows " + std::to_string(p.nGRows) +
@@ -1256,6 +1262,18 @@ extern "C" int dnas_tierc_precompile(const dnas_flat_model* fm, int32_t members,
   }
 }
 
+namespace {
+// members = 1: the tier-A plan, else the cluster plan -- under the row program a model of this machine follows (record, environment)
+dnas::TierAPlan plan_as_a_model_would(const dnas_flat_model* fm, int members) {
+  if (members == 1) {
+    const int threads = env_threads(dnas::kTierAThreads);
+    return dnas::buildTierAPlan(*fm, threads, env_or_recorded_choice(fm, 1, threads));
+  }
+  const int threads = env_threads(0);
+  return dnas::chooseClusterPlan(*fm, members, threads, env_or_recorded_choice(fm, members >= 2 ? members : 0, threads));
+}
+}  // namespace
+
 // Analysis / test aid: the tier-C tables of a machine exactly as the kernel receives them (no GPU needed).
 // info[8] = {G, K, T, entries per member, S stripes, exchange rows, proxies, 0}; every other output may be NULL:
 // row_shapes[K][6], entries[G][n_entries][T], meta[G][K][T], member_of[N], lds_index[N] = row*T + lane inside
@@ -1265,7 +1283,7 @@ extern "C" int dnas_tierc_plan(const dnas_flat_model* fm, int32_t members, int32
                                uint32_t* fold) {
   if (!fm || !info) return dnas::fail(DNAS_E_INVALID, "null argument");
   try {
-    const dnas::TierAPlan p = members == 1 ? dnas::buildTierAPlan(*fm) : dnas::chooseClusterPlan(*fm, members, 0);
+    const dnas::TierAPlan p = plan_as_a_model_would(fm, members);
     if (!p.ok) return dnas::fail(DNAS_E_UNSUPPORTED, p.whyNot);
     info[0] = p.G; info[1] = p.K; info[2] = p.T; info[3] = p.nEntries; info[4] = p.nSRows; info[5] = p.nGRows; info[6] = (int32_t)p.proxyMember.size(); info[7] = 0;
     if (row_shapes)
@@ -1296,7 +1314,7 @@ extern "C" int dnas_tierc_plan(const dnas_flat_model* fm, int32_t members, int32
 extern "C" int dnas_tierc_plan_proxies(const dnas_flat_model* fm, int32_t members, int32_t* proxy_member, int32_t* proxy_lds_index, size_t cap) {
   if (!fm || !proxy_member || !proxy_lds_index) return dnas::fail(DNAS_E_INVALID, "null argument");
   try {
-    const dnas::TierAPlan p = members == 1 ? dnas::buildTierAPlan(*fm) : dnas::chooseClusterPlan(*fm, members, 0);
+    const dnas::TierAPlan p = plan_as_a_model_would(fm, members);
     if (!p.ok) return dnas::fail(DNAS_E_UNSUPPORTED, p.whyNot);
     if (cap < p.proxyMember.size()) return dnas::fail(DNAS_E_INVALID, "proxy buffer too small");
     if (!p.proxyMember.empty()) {
@@ -1350,7 +1368,7 @@ extern "C" int dnas_tiera_plan_slots(const dnas_flat_model* fm, int32_t* lds_ind
                                      int32_t* rows) {
   if (!fm) return dnas::fail(DNAS_E_INVALID, "null argument");
   try {
-    const dnas::TierAPlan p = dnas::buildTierAPlan(*fm);
+    const dnas::TierAPlan p = plan_as_a_model_would(fm, 1);
     if (!p.ok) return dnas::fail(DNAS_E_UNSUPPORTED, p.whyNot);
     if (threads) *threads = p.T;
     if (rows) *rows = p.K;

@@ -27,10 +27,12 @@
 // exchange buffer in global memory -- a mailbox: the thread that holds the edge's source state is its only
 // writer and stores what it offers (the value only grows within a column: no atomic), and thread t of the owner
 // folds cell r*T + t into the destination state's LDS accumulators once per sweep (sc1 loads issued behind the
-// last row of a sweep, ds_max in front of the first row of the next).  The launcher places a cluster on one XCD
-// (blockIdx b and b+8 share one); the members compare their XCC ids at the first barrier: on one XCD the
-// stores are plain -- the cells live in that XCD's L2 and never travel to memory --, a split cluster stores
-// write-through (sc1), so the protocol is correct wherever the work-groups run.  Termination is agreed in two
+// last row of a sweep, ds_max in front of the first row of the next).  The launcher either places a cluster on one
+// XCD (blockIdx b and b+8 share one) or -- large clusters, of which whole ones per XCD would leave CUs idle -- deals its
+// members over the XCDs (`spread`: neighbouring blocks; runtime.hip decides, option cluster_spread).  The members compare
+// their XCC ids at the first barrier: on one XCD the stores are plain -- the cells live in that XCD's L2 and never travel
+// to memory --, a split cluster stores write-through (sc1), so the protocol is correct wherever the work-groups run (a
+// cluster that was meant to share an XCD and does not, included).  Termination is agreed in two
 // levels: inside a work-group as before, across the cluster through a device-scope epoch GE (bumped after
 // every batch of exchange offers has completed) and one idle word per member.
 //
@@ -246,7 +248,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
                    int nClusters, int nReads, unsigned long long timeoutTicks,   // watchdog per lattice column (100 MHz ticks)
                    unsigned long long arriveTicks,    // ... and for the members of a cluster to have all started
                    const int* __restrict__ colRange,     // [nReads][2] first and last column to fill, or null: 0 .. L
-                   int spread) {                         // tier C, tests: 1 = the members of a cluster are NEIGHBOURING blocks (different XCDs)
+                   int spread) {                         // tier C: 1 = the members of a cluster are NEIGHBOURING blocks (dealt over the XCDs: 21-member clusters, tests)
   extern __shared__ double lds[];
   extern __shared__ unsigned ldsU[];
   constexpr int T = DNAS_T, K = DNAS_K, D_ = DNAS_D, lanes = 2, NSm = DNAS_NS, NS = DNAS_NS * DNAS_G;   // stored lanes: S, D

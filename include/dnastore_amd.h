@@ -127,7 +127,13 @@ int dnas_model_create(const dnas_flat_model *fm, int device_id, size_t arena_byt
 /* The same with options, "key=value,key=value" (NULL: none).  Keys: tier = A | B | C (force a fill kernel; failing
  * to provide it is then an error), cluster = work-groups per read for tier C, threads = 512 | 1024 per work-group
  * (default 1024 for tier A; tier C takes 512 when the machine then fits fewer work-groups), max_clusters, max_slots (reads per
- * fill launch), cluster_timeout_s (tier C watchdog per lattice column), checkpoint = auto | always | never and
+ * fill launch), cluster_spread = 0 | 1 (tier C: the members of a cluster dealt over the XCDs -- their exchange then goes through
+ * memory instead of one XCD's L2; default: when that fits a quarter more clusters on the chip), cluster_timeout_s (tier C
+ * watchdog per lattice column, default 30 s) and cluster_arrive_s (how long the first barrier of a launch waits for work-groups
+ * of a cluster that have not been STARTED yet because something else holds their CUs, default 120 s: the members of a cluster
+ * wait for each other, so a launch needs all of them resident; when either time runs out the launch is abandoned and the call
+ * returns DNAS_E_DEVICE -- until then the waiting work-groups keep their CUs), tb_threads = reads per block of the
+ * thread-per-read traceback (multiple of 64, default 128), checkpoint = auto | always | never and
  * segment = columns (bounded-memory decode of reads whose lattice -- the reference's ViterbiMatrix::cell,
  * viterbi.h:48-50 -- does not fit the arena: segments of the lattice are filled from checkpoints and traced back one
  * after the other; results are bit-identical), traceback = thread, arena_fraction, plan_order = 0 | 1 | 2 and plan_slack = 0 .. 8
@@ -168,7 +174,9 @@ int dnas_viterbi_batch_device(dnas_model *model, int64_t n_reads, const uint64_t
 int dnas_model_sync(dnas_model *model);
 
 /* Which fill kernel serves this model: "tier A: <shape>" (register/LDS-resident kernel, JIT-specialised
- * for the machine) or "tier B: <reason>" (general global-memory kernel).  DNAS_TIER=B forces tier B. */
+ * for the machine; "...W8 ... 2 work-groups per CU": a small row program compiled so that two reads share a CU), "tier C: <n>
+ * work-groups per read, ..." (the same kernel on a cluster of work-groups) or "tier B: <reason>" (general global-memory
+ * kernel); behind it the tuning record that chose the row program.  DNAS_TIER=B forces tier B. */
 const char *dnas_model_tier(const dnas_model *model);
 /* Keep the traceback's event log (see dnas_decode_fastseqs_ex) for the following calls; dnas_model_read_events
  * returns the events of read `read_index` of the last call (out may be NULL to ask for the count). */

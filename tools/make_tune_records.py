@@ -48,10 +48,24 @@ for name, m, payload, n_reads, members in machines:
         results.append((order, slack, min(ms[1:])))
     best = results[0]
     fastest = min(results, key=lambda r: r[2])
+    confirm = ""
     if fastest[2] < 0.96 * best[2]:      # the default dealing stays unless another is 4 % faster: the timings repeat to 1-3 %
-        best = fastest
-    text = "order=%d slack=%d kernel=%s   (fill of %d bench reads, %s;%s)\n" % (best[0], best[1], da.FlatModel.kernel_source_hash(), n_reads, name,
-                                                                               "".join("  %d/%d: %.2f ms" % r for r in results))
+        # ... and the verdict must REPRODUCE: a fresh model of the winner and of the default, three timed runs each, medians (one fast
+        # sample among slower neighbours -- round 3's s16mr2l4c4 record -- does not replace the default)
+        def median_ms(order, slack):
+            dec = da.ViterbiDecoder(m, params, options="tier=%s,plan_order=%d,plan_slack=%d" % ("A" if members == 1 else "C", order, slack))
+            ms = []
+            for rep in range(4):
+                dec.decode(reads)
+                ms.append(dec.stats()["fill_ms"])
+            dec.close()
+            return sorted(ms[1:])[1]
+        again_w, again_d = median_ms(fastest[0], fastest[1]), median_ms(best[0], best[1])
+        confirm = "  confirmation (medians of three): %d/%d %.2f ms, %d/%d %.2f ms" % (fastest[0], fastest[1], again_w, best[0], best[1], again_d)
+        if again_w < 0.97 * again_d:
+            best = fastest
+    text = "order=%d slack=%d kernel=%s   (fill of %d bench reads, %s;%s;%s)\n" % (best[0], best[1], da.FlatModel.kernel_source_hash(), n_reads, name,
+                                                                                  "".join("  %d/%d: %.2f ms" % r for r in results), confirm)
     path = os.path.join(OUT, fm.tune_record_name(members))
     open(path, "w").write(text)
     print(os.path.basename(path), text.strip(), flush=True)

@@ -15,11 +15,11 @@ root = "$R/gpurun_out/pmc_fb"
 tot, meta = {}, {}
 for f in sorted(glob.glob(os.path.join(root, "*", "run_counter_collection.csv"))):
     for r in csv.DictReader(open(f)):
-        if "fwdback_onchip16" not in r["Kernel_Name"]: continue
+        if "fwdback_onchip" not in r["Kernel_Name"]: continue
         tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
         meta = {"grid": int(r["Grid_Size"]), "workgroup": int(r["Workgroup_Size"]), "vgpr": int(r["VGPR_Count"]), "agpr": r.get("Accum_VGPR_Count"), "lds": int(r["LDS_Block_Size"]), "scratch": int(r["Scratch_Size"]),
                 "ns": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])}
-out = {"workload": "one E-step over 125 000 pairs (bench.py --config 4 --steps 1 --warmup 0 --timed-only), 16-lane kernel", "dispatch": meta, "counters": tot}
+out = {"workload": "one E-step over 125 000 pairs (bench.py --config 4 --steps 1 --warmup 0 --timed-only), all wavefront kernels (8x16: 93 % of the pairs)", "dispatch": meta, "counters": tot}
 if "SQ_WAVE_CYCLES" in tot:
     pairs = 125000.0
     out["derived"] = {"valu_per_pair": tot.get("SQ_INSTS_VALU", 0) / pairs * 1.0, "salu_per_pair": tot.get("SQ_INSTS_SALU", 0) / pairs, "lds_per_pair": tot.get("SQ_INSTS_LDS", 0) / pairs,
