@@ -374,7 +374,7 @@ def viterbi_line(ctx, config, variant, n_reads, steps, warmup, cpu_seconds, time
         # and is NOT measured in this run: the field carries a recorded per-column figure only when a profile of this
         # configuration and kernel specialisation exists, with its source named; otherwise null.
         traffic, traffic_source = None, None
-        for rnd in ("r3", "r2"):
+        for rnd in ("r4", "r3", "r2"):
             try:
                 src = os.path.join("profiles", "%s_traffic_config%d%s.json" % (rnd, config, variant if config == 3 else ""))
                 tj = json.load(open(os.path.join(ROOT, src)))

@@ -144,14 +144,15 @@ def fwdback_line(ctx, n_pairs, steps, warmup, cpu_seconds, timed_only):
         # SIMD every four cycles: 256 CUs x 4 SIMDs x 2.4 GHz / 4.
         issue = None
         try:
-            sq = json.load(open(os.path.join(ROOT, "profiles", "r3_sq_counters_fwdback.json")))
+            sq_file = next(f for f in ("r4_sq_counters_fwdback.json", "r3_sq_counters_fwdback.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            sq = json.load(open(os.path.join(ROOT, "profiles", sq_file)))
             per_pair = sq["derived"]["valu_per_pair"]
             peak = 256 * 4 * 2.4e9 / 4
             ach = per_pair * total_pairs * steps / elapsed / max(world, 1)
             issue = {"bound": "fp64 vector issue", "achieved": ach, "peak": peak, "unit": "wave instructions/s per GPU", "frac": ach / peak,
-                     "valu_wave_instructions_per_pair": per_pair, "source": "profiles/r3_sq_counters_fwdback.json (SQ_INSTS_VALU of one E-step / pairs)",
+                     "valu_wave_instructions_per_pair": per_pair, "source": "profiles/%s (SQ_INSTS_VALU of one E-step / pairs)" % sq_file,
                      "valu_active_share_of_wave_cycles": sq["derived"].get("valu_issue_share_of_wave_cycles")}
-        except (OSError, ValueError, KeyError):
+        except (OSError, ValueError, KeyError, StopIteration):
             pass
         # HBM traffic of the E-step kernels: a recorded per-pair figure of separate rocprofv3 --pmc passes of this command (never
         # measured in the bench run), newest round first; null when no profile exists

@@ -192,6 +192,30 @@ def test_config4b_hamming74_water64_composite_tier_c(da, oracle_mod, ref_data):
     dec.close()
 
 
+def test_config4b_full_lattice_on_clusters_dealt_over_the_xcds(da, oracle_mod, ref_data):
+    """The 258 538-state machine as it ships: 21 work-groups per read, the members of a cluster DEALT OVER THE XCDs (the default for
+    clusters this large: exchange through memory, write-through stores), 20 proxies.  Every cell of the lattice of a short read --
+    6 lanes x 258 538 states x 25 columns -- against the oracle, and the census says the cluster really was split."""
+    O = oracle_mod
+    m = _compose(da, ref_data, "hamming74.json", da.Machine.fromJSON(DROPDOT), "water64.1.json", "l4c4.json")
+    dec = da.ViterbiDecoder(m, da.MutatorParams.fromFlags(global_=True))
+    try:
+        assert dec.tier.startswith("tier C: 21 work-groups") and "dealt over the XCDs" in dec.tier, dec.tier
+        rng = random.Random(29)
+        read = _substitute(rng, m.encodeBytes(bytes(rng.randrange(256) for _ in range(32)))[:24], 0.05)
+        out, ll, st = dec.decode([read])
+        clusters, split = dec.cluster_census()
+        assert (clusters, split) == (1, 1), (clusters, split)
+        orc = O.ViterbiOracle(O.Machine.from_json(m.toJSON()), O.MutatorParams.from_cli(global_=True))
+        s, oll, olat = orc.decode(read, want_lattice=True)
+        assert out[0] == s and ll[0] == oll and st[0] == 0
+        lat = dec.lattice(0, len(read))
+        for p in range(len(read) + 1):          # column by column: the transposed copy of the whole lattice would be another 300 MB
+            assert np.array_equal(np.ascontiguousarray(lat[p].T).view(np.uint64), olat[p].view(np.uint64)), "column %d" % p
+    finally:
+        dec.close()
+
+
 @pytest.mark.parametrize("mach,fa,flags,members", [("s16mr2l4c4.json", "hello.s16mr2.fa", dict(global_=True), 3), ("s16h74l4c4.json", "hello.s16h74.del.fa", dict(), 4),
                                                    ("s16h74l4c4.json", "hello.s16h74.del.fa", dict(global_=True), 2)])
 def test_tier_c_proxies_full_lattice_bit_exact(da, oracle_mod, ref_data, monkeypatch, mach, fa, flags, members):

@@ -18,6 +18,8 @@ bash tools/profile_round3.sh config1 --config 1 --reads 64
 bash tools/profile_round3.sh config3 --config 3 --reads 2400
 bash tools/profile_round3.sh config3b --config 3 --variant b --reads 12
 bash tools/profile_round3.sh config4 --config 4 --reads 125000
+fi
+if [ $PART = all ] || [ $PART = a2 ]; then
 log "100k reads"
 timeout -k 10 900 python bench.py --config 2 --reads 100000 --steps 1 --warmup 1 --cpu-seconds 0 --no-other-configs > $P/bench_config2_100k.json 2> $P/bench_config2_100k.err || log "100k FAILED"
 log "1M pairs"
