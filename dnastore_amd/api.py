@@ -421,10 +421,19 @@ class ForwardBackward:
     """A database of alignment pairs resident on one GPU (dnas_fb): load once, run the E-step many times."""
 
     def __init__(self, pairs, device=0):
+        """pairs: a StockholmDB, the packed dict of its arrays(), or None (an empty handle: load() later)."""
         self._h = ctypes.c_void_p()
+        self.n = 0
         _l.check(_l.lib().dnas_fb_create(int(device), ctypes.byref(self._h)))
+        if pairs is not None:
+            self.load(pairs)
+
+    def load(self, pairs):
+        """dnas_fb_load_pairs: the database goes to the GPU (replacing the one that was there)."""
         pk = pairs.arrays() if isinstance(pairs, StockholmDB) else pairs
-        keep, ptrs = _pair_ptrs(pk)
+        ptrs = pk.get("_ptrs") if isinstance(pk, dict) else None
+        if ptrs is None:
+            keep, ptrs = _pair_ptrs(pk)
         self.n = int(pk["n"])
         _l.check(_l.lib().dnas_fb_load_pairs(self._h, self.n, *ptrs))
 

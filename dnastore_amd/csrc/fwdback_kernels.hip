@@ -227,3 +227,69 @@ fwdback_reduce_kernel(const double* __restrict__ pairCounts, const double* __res
     __syncthreads();
   }
 }
+
+// ---- database checks and the envelope census on the GPU (dnas_fb_load_pairs / the routing of dnas_fb_estep) ----------------
+// What the host did in loops over every base and guide column of the database (a quarter of a second for 125 000 pairs).
+
+// flags[0] |= 1: a base outside 0..3; |= 2: a guide column array that decreases.  One thread per pair.
+extern "C" __global__ void __launch_bounds__(256)
+fwdback_validate_kernel(int64_t nPairs, const int8_t* __restrict__ inSeqs, const int64_t* __restrict__ inOff,
+                        const int8_t* __restrict__ outSeqs, const int64_t* __restrict__ outOff, const int32_t* __restrict__ cmIn,
+                        const int64_t* __restrict__ cmInOff, const int32_t* __restrict__ cmOut, const int64_t* __restrict__ cmOutOff,
+                        unsigned* __restrict__ flags) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nPairs) return;
+  unsigned bad = 0;
+  const int64_t I = inOff[i + 1] - inOff[i], O = outOff[i + 1] - outOff[i];
+  const int8_t* in = inSeqs + inOff[i];
+  const int8_t* out = outSeqs + outOff[i];
+  const int32_t* ci = cmIn + cmInOff[i];
+  const int32_t* co = cmOut + cmOutOff[i];
+  for (int64_t k = 0; k < I; ++k) { if (in[k] < 0 || in[k] > 3) bad |= 1u; if (ci[k + 1] < ci[k]) bad |= 2u; }
+  for (int64_t k = 0; k < O; ++k) { if (out[k] < 0 || out[k] > 3) bad |= 1u; if (co[k + 1] < co[k]) bad |= 2u; }
+  if (bad) atomicOr(flags, bad);
+}
+
+// The envelope of every pair (alignpath.h:48-53: op in [lo(ip), hi(ip)] <=> |cm(ip) - cm(op)| <= maxDistance) in one pass per
+// pair: cells = sum of the row widths, width = the widest row, steps = the anti-diagonals of its wavefront, and whether half the
+// lanes of the wavefront kernels do (fwdback_onchip.hip: hi(ip) - lo(ip + W) < W for every row; W = 8 and 16).
+// census[i] = {cells, width | fits8 << 16 | fits16 << 17, steps}.  One thread per pair; three two-pointer scans in step
+// (rows ip, ip - 8 and ip - 16).
+extern "C" __global__ void __launch_bounds__(256)
+fwdback_census_kernel(int64_t nPairs, int maxDistance, const int64_t* __restrict__ inOff, const int64_t* __restrict__ outOff,
+                      const int32_t* __restrict__ cmIn, const int64_t* __restrict__ cmInOff, const int32_t* __restrict__ cmOut,
+                      const int64_t* __restrict__ cmOutOff, int64_t* __restrict__ census) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nPairs) return;
+  const int64_t I = inOff[i + 1] - inOff[i], O = outOff[i + 1] - outOff[i];
+  const int32_t* ci = cmIn + cmInOff[i];
+  const int32_t* co = cmOut + cmOutOff[i];
+  const int Dm = maxDistance;
+  // scan q = 0: row ip; q = 1: row ip - 8; q = 2: row ip - 16 (only its hi is needed)
+  int64_t lo[3] = {0, 0, 0}, hi[3] = {-1, -1, -1};
+  auto advance = [&](int q, int64_t ip) {
+    while (lo[q] <= O && co[lo[q]] < ci[ip] - Dm) ++lo[q];
+    if (hi[q] < lo[q] - 1) hi[q] = lo[q] - 1;
+    while (hi[q] + 1 <= O && co[hi[q] + 1] <= ci[ip] + Dm) ++hi[q];
+  };
+  int64_t cells = 0, lo0 = 0;
+  int width = 1;
+  bool fits8 = true, fits16 = true;
+  for (int64_t ip = 0; ip <= I; ++ip) {
+    advance(0, ip);
+    if (ip == 0) lo0 = lo[0];
+    cells += hi[0] - lo[0] + 1;
+    width = max(width, (int)(hi[0] - lo[0] + 1));
+    if (ip >= 8) {
+      advance(1, ip - 8);
+      if (hi[1] >= lo[1] && hi[1] - lo[0] >= 8) fits8 = false;       // (an empty row holds no lane)
+    }
+    if (ip >= 16) {
+      advance(2, ip - 16);
+      if (hi[2] >= lo[2] && hi[2] - lo[0] >= 16) fits16 = false;
+    }
+  }
+  census[3 * i] = cells > 0 ? cells : 1;
+  census[3 * i + 1] = (int64_t)width | ((int64_t)(fits8 ? 1 : 0) << 16) | ((int64_t)(fits16 ? 1 : 0) << 17);
+  census[3 * i + 2] = I + (hi[0] > 0 ? hi[0] : 0) - lo0 + 1;
+}

@@ -31,6 +31,10 @@ extern "C" __global__ void fwdback_onchip16x16p6_kernel(FB_ONCHIP_ARGS);
 extern "C" __global__ void fwdback_onchip16x32p6_kernel(FB_ONCHIP_ARGS);
 extern "C" __global__ void fwdback_onchip32x32p6_kernel(FB_ONCHIP_ARGS);
 extern "C" __global__ void fwdback_reduce_kernel(const double*, const double*, int64_t, int, double*);
+extern "C" __global__ void fwdback_validate_kernel(int64_t, const int8_t*, const int64_t*, const int8_t*, const int64_t*, const int32_t*,
+                                                   const int64_t*, const int32_t*, const int64_t*, unsigned*);
+extern "C" __global__ void fwdback_census_kernel(int64_t, int, const int64_t*, const int64_t*, const int32_t*, const int64_t*, const int32_t*,
+                                                 const int64_t*, int64_t*);
 
 #define HIP_TRY(expr)                                                                          \
   do {                                                                                         \
@@ -79,8 +83,7 @@ struct dnas_fb {
   int64_t nPairs = 0;
   int P = -1;                    // pLen size the per-pair buffers are sized for
   int maxInLen = 0;
-  std::vector<int64_t> inOff, outOff, ciOff, coOff;          // host copies (envelope census)
-  std::vector<int32_t> ci, co;
+  std::vector<int64_t> inOff, outOff;                        // host copies of the sequence offsets (routing by length, statistics)
   int8_t *dIn = nullptr, *dOut = nullptr;
   int64_t *dInOff = nullptr, *dOutOff = nullptr, *dCiOff = nullptr, *dCoOff = nullptr;
   int32_t *dCi = nullptr, *dCo = nullptr;
@@ -168,19 +171,14 @@ extern "C" int dnas_fb_load_pairs(dnas_fb* h, int64_t n_pairs, const int8_t* in_
   HIP_TRY(hipStreamSynchronize(h->stream));
   fbFreeDatabase(h);
   if (n_pairs == 0) return DNAS_OK;
-  // ---- validate (the kernels trust these)
+  // ---- validate (the kernels trust these): the offsets here, every base and guide column on the GPU once they are there
   int maxIn = 0;
+  if (in_off[0] != 0 || out_off[0] != 0 || cm_in_off[0] != 0 || cm_out_off[0] != 0) return dnas::fail(DNAS_E_INVALID, "offset arrays must start at 0");
   for (int64_t i = 0; i < n_pairs; ++i) {
     const int64_t inLen = in_off[i + 1] - in_off[i], outLen = out_off[i + 1] - out_off[i];
     if (inLen < 0 || outLen < 0 || cm_in_off[i + 1] - cm_in_off[i] != inLen + 1 || cm_out_off[i + 1] - cm_out_off[i] != outLen + 1)
       return dnas::fail(DNAS_E_INVALID, "pair " + std::to_string(i) + ": inconsistent offsets");
     if (inLen > 30000 || outLen > 30000) return dnas::fail(DNAS_E_UNSUPPORTED, "pair " + std::to_string(i) + ": sequences longer than 30000");
-    const int32_t* ci = cm_in + cm_in_off[i];
-    const int32_t* co = cm_out + cm_out_off[i];
-    for (int64_t k = 0; k < inLen; ++k) if (in_seqs[in_off[i] + k] < 0 || in_seqs[in_off[i] + k] > 3) return dnas::fail(DNAS_E_BAD_BASE, "bad base");
-    for (int64_t k = 0; k < outLen; ++k) if (out_seqs[out_off[i] + k] < 0 || out_seqs[out_off[i] + k] > 3) return dnas::fail(DNAS_E_BAD_BASE, "bad base");
-    for (int64_t k = 0; k < inLen; ++k) if (ci[k + 1] < ci[k]) return dnas::fail(DNAS_E_INVALID, "cm_in must be non-decreasing");
-    for (int64_t k = 0; k < outLen; ++k) if (co[k + 1] < co[k]) return dnas::fail(DNAS_E_INVALID, "cm_out must be non-decreasing");
     maxIn = std::max<int>(maxIn, (int)inLen);
   }
   auto cleanup2 = [&] { fbFreeDatabase(h); };
@@ -196,15 +194,23 @@ extern "C" int dnas_fb_load_pairs(dnas_fb* h, int64_t n_pairs, const int8_t* in_
   UPLOAD(h->dCiOff, cm_in_off, (size_t)n_pairs + 1, int64_t) UPLOAD(h->dCoOff, cm_out_off, (size_t)n_pairs + 1, int64_t)
 #undef UPLOAD
   HIP_TRY(hipMalloc((void**)&h->dLL, (size_t)n_pairs * sizeof(double)));
+  {
+    // every base in 0..3, every guide column array non-decreasing: one thread per pair (h->dLseOps doubles as the flag word)
+    HIP_TRY(hipMemsetAsync(h->dLseOps, 0, sizeof(unsigned long long), h->stream));
+    hipLaunchKernelGGL(fwdback_validate_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, h->stream, n_pairs, h->dIn, h->dInOff, h->dOut,
+                       h->dOutOff, h->dCi, h->dCiOff, h->dCo, h->dCoOff, (unsigned*)h->dLseOps);
+    HIP_TRY(hipGetLastError());
+    unsigned flags = 0;
+    HIP_TRY(hipMemcpyAsync(&flags, h->dLseOps, sizeof flags, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (flags & 1u) { cleanup(); return dnas::fail(DNAS_E_BAD_BASE, "bad base"); }
+    if (flags & 2u) { cleanup(); return dnas::fail(DNAS_E_INVALID, "cm_in / cm_out must be non-decreasing"); }
+  }
 #undef cleanup
   h->nPairs = n_pairs;
   h->maxInLen = maxIn;
   h->inOff.assign(in_off, in_off + n_pairs + 1);
   h->outOff.assign(out_off, out_off + n_pairs + 1);
-  h->ciOff.assign(cm_in_off, cm_in_off + n_pairs + 1);
-  h->coOff.assign(cm_out_off, cm_out_off + n_pairs + 1);
-  h->ci.assign(cm_in, cm_in + nCi);
-  h->co.assign(cm_out, cm_out + nCo);
   return DNAS_OK;
 }
 
@@ -256,45 +262,50 @@ extern "C" int dnas_fb_estep(dnas_fb* h, const dnas_mutator_params* p, int stric
     for (int& v : rt.maxInOnchip) v = 0;
     for (int& v : rt.maxSteps) v = 1;
     const bool noNarrow = getenv("DNAS_FB_NO_NARROW") != nullptr;       // (measurement: the round-3 routing, W = the row capacity)
-    std::vector<int> rowLo, rowHi;
+    // the envelope census of every pair -- cells, widest row, wavefront steps, whether half the lanes do -- on the GPU
+    // (fwdback_census_kernel: one thread per pair; on the host this loop took longer than the E-step itself)
+    std::vector<int64_t> census((size_t)n_pairs * 3);
+    {
+      int64_t* dCensus = nullptr;
+      HIP_TRY(hipMalloc((void**)&dCensus, census.size() * sizeof(int64_t)));
+      hipLaunchKernelGGL(fwdback_census_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, h->stream, n_pairs, Dm, h->dInOff, h->dOutOff,
+                         h->dCi, h->dCiOff, h->dCo, h->dCoOff, dCensus);
+      hipError_t e = hipGetLastError();
+      if (e == hipSuccess) e = hipMemcpyAsync(census.data(), dCensus, census.size() * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+      (void)hipFree(dCensus);
+      HIP_TRY(e);
+    }
     for (int64_t i = 0; i < n_pairs; ++i) {
       const int64_t inLen = h->inOff[i + 1] - h->inOff[i], outLen = h->outOff[i + 1] - h->outOff[i];
-      const int32_t* ci = h->ci.data() + h->ciOff[i];
-      const int32_t* co = h->co.data() + h->coOff[i];
-      int64_t lo = 0, hi = -1, tot = 0;
-      int w = 1;
-      rowLo.assign((size_t)inLen + 1, 0); rowHi.assign((size_t)inLen + 1, -1);
-      for (int64_t ip = 0; ip <= inLen; ++ip) {
-        while (lo <= outLen && co[lo] < ci[ip] - Dm) ++lo;
-        if (hi < lo - 1) hi = lo - 1;
-        while (hi + 1 <= outLen && co[hi + 1] <= ci[ip] + Dm) ++hi;
-        tot += hi - lo + 1;
-        w = std::max<int>(w, (int)(hi - lo + 1));
-        rowLo[(size_t)ip] = (int)lo; rowHi[(size_t)ip] = (int)hi;
-      }
-      rt.cells[(size_t)i] = std::max<int64_t>(tot, 1);
+      const int w = (int)(census[3 * (size_t)i + 1] & 0xffff);
+      const bool fits8 = (census[3 * (size_t)i + 1] >> 16) & 1, fits16 = (census[3 * (size_t)i + 1] >> 17) & 1;
+      rt.cells[(size_t)i] = census[3 * (size_t)i];
       rt.width[(size_t)i] = w;
       int kind = w <= 16 ? 1 : (w <= 32 ? 3 : 4);            // the full-width kernel of the row capacity ...
-      if (kind < 4 && !noNarrow) {
-        // ... or half the lanes, when every lane has left its row before its next one comes up (Forward: rows ip, ip + W;
-        // Backward walks the same rows the other way: the same inequalities)
-        const int W = kFbLanes[kind - 1];
-        bool fits = true;
-        for (int64_t ip = 0; ip + W <= inLen && fits; ++ip)
-          fits = rowHi[(size_t)ip] < rowLo[(size_t)ip] /* empty row */ || rowHi[(size_t)ip] - rowLo[(size_t)(ip + W)] < W;
-        if (fits) --kind;
-      }
+      // ... or half the lanes, when every lane has left its row before its next one comes up (Forward: rows ip, ip + W;
+      // Backward walks the same rows the other way: the same inequalities)
+      if (kind < 4 && !noNarrow && (kind == 1 ? fits8 : fits16)) --kind;
       const bool chip = kind < 4 && P <= 8 && inLen <= longest[kind] && outLen < 32000 && !forceStreaming;
       (chip ? rt.onchip[kind] : rt.streaming).push_back(i);
       if (chip) {
         rt.maxInOnchip[kind] = std::max<int>(rt.maxInOnchip[kind], (int)inLen);
-        // the steps of the pair's wavefront: a = ip + op from lo(0) to inLen + hi(inLen)
-        rt.maxSteps[kind] = std::max<int>(rt.maxSteps[kind], (int)inLen + std::max(rowHi[(size_t)inLen], 0) - rowLo[0] + 1);
+        rt.maxSteps[kind] = std::max<int>(rt.maxSteps[kind], (int)census[3 * (size_t)i + 2]);   // a = ip + op from lo(0) to inLen + hi(inLen)
       }
     }
     // the pairs of a wave walk in step: neighbours in the list should be of a length (longest first)
-    for (auto& list : rt.onchip)
-      std::stable_sort(list.begin(), list.end(), [&](int64_t x, int64_t y) { return h->inOff[x + 1] - h->inOff[x] > h->inOff[y + 1] - h->inOff[y]; });
+    // (a stable counting sort by input length: the lengths are at most 30 000, the lists 10^5 .. 10^6 long)
+    for (auto& list : rt.onchip) {
+      if (list.size() < 2) continue;
+      int64_t longestIn = 0;
+      for (int64_t x : list) longestIn = std::max(longestIn, h->inOff[x + 1] - h->inOff[x]);
+      std::vector<int64_t> start((size_t)longestIn + 2, 0);
+      for (int64_t x : list) ++start[(size_t)(longestIn - (h->inOff[x + 1] - h->inOff[x])) + 1];
+      for (size_t k = 1; k < start.size(); ++k) start[k] += start[k - 1];
+      std::vector<int64_t> sorted(list.size());
+      for (int64_t x : list) sorted[(size_t)start[(size_t)(longestIn - (h->inOff[x + 1] - h->inOff[x]))]++] = x;
+      list.swap(sorted);
+    }
     auto put = [&](const std::vector<int64_t>& v, int64_t** d) -> hipError_t {
       hipError_t e = hipMalloc((void**)d, std::max<size_t>(v.size(), 1) * sizeof(int64_t));
       if (e == hipSuccess && !v.empty()) e = hipMemcpy(*d, v.data(), v.size() * sizeof(int64_t), hipMemcpyHostToDevice);
