@@ -30,6 +30,42 @@ std::string tempName(const std::string& path) {
   return path + "." + std::to_string((long)getpid()) + "." + std::to_string(counter.fetch_add(1)) + ".tmp";
 }
 
+// hiprtc through a handle of its own: the library does not link it (a machine with a warm kernel cache needs no compiler), and
+// DNAS_HIPRTC_LIBRARY names another one.  NOTE what this does NOT cure: a process that has loaded PyTorch already holds PyTorch's
+// bundled libhiprtc.so.7 / libamd_comgr.so.3 (another ROCm release's compiler under the SAME sonames), and whatever asks for those
+// sonames afterwards -- the system's hiprtc asking for comgr included -- gets PyTorch's copies.  The same source then compiles to
+// other code than build() makes with the system's compiler (measured: water64.1*l4c4's 64-register kernel spills 31 registers
+// instead of 5 and runs 15 % slower; the 128-register kernels differ by 1 %).  The code objects of the fixture and bench machines
+// therefore ship precompiled (dnastore_amd/kcache/, __graft_entry__.build()); INTEGRATION.md section 6.
+struct Hiprtc {
+  void* lib = nullptr;
+  hiprtcResult (*version)(int*, int*) = nullptr;
+  hiprtcResult (*create)(hiprtcProgram*, const char*, const char*, int, const char**, const char**) = nullptr;
+  hiprtcResult (*compile)(hiprtcProgram, int, const char**) = nullptr;
+  hiprtcResult (*logSize)(hiprtcProgram, size_t*) = nullptr;
+  hiprtcResult (*log)(hiprtcProgram, char*) = nullptr;
+  hiprtcResult (*codeSize)(hiprtcProgram, size_t*) = nullptr;
+  hiprtcResult (*code)(hiprtcProgram, char*) = nullptr;
+  hiprtcResult (*destroy)(hiprtcProgram*) = nullptr;
+  const char* (*errorString)(hiprtcResult) = nullptr;
+  std::string where;
+  Hiprtc() {
+    const char* names[] = {getenv("DNAS_HIPRTC_LIBRARY"), "/opt/rocm/lib/libhiprtc.so.7", "libhiprtc.so.7", "libhiprtc.so"};
+    for (const char* n : names) {
+      if (!n || !*n) continue;
+      if ((lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND))) { where = n; break; }
+    }
+    if (!lib) return;
+#define DNAS_RTC_SYM(field, name) field = reinterpret_cast<decltype(field)>(dlsym(lib, name))
+    DNAS_RTC_SYM(version, "hiprtcVersion"); DNAS_RTC_SYM(create, "hiprtcCreateProgram"); DNAS_RTC_SYM(compile, "hiprtcCompileProgram");
+    DNAS_RTC_SYM(logSize, "hiprtcGetProgramLogSize"); DNAS_RTC_SYM(log, "hiprtcGetProgramLog"); DNAS_RTC_SYM(codeSize, "hiprtcGetCodeSize");
+    DNAS_RTC_SYM(code, "hiprtcGetCode"); DNAS_RTC_SYM(destroy, "hiprtcDestroyProgram"); DNAS_RTC_SYM(errorString, "hiprtcGetErrorString");
+#undef DNAS_RTC_SYM
+  }
+  bool ok() const { return lib && version && create && compile && logSize && log && codeSize && code && destroy && errorString; }
+};
+const Hiprtc& hiprtc() { static Hiprtc h; return h; }
+
 std::string slurp(const std::string& path) {
   std::ifstream in(path, std::ios::binary);
   if (!in) throw std::runtime_error("cannot read " + path);
@@ -118,8 +154,9 @@ std::vector<char> jitCompile(const std::string& defines, const std::string& key)
   static std::mutex jitMutex;
   std::lock_guard<std::mutex> lock(jitMutex);
   const std::string src = tieraSource();
+  const Hiprtc& rtc = hiprtc();
   int rtcMajor = 0, rtcMinor = 0;
-  (void)hiprtcVersion(&rtcMajor, &rtcMinor);
+  if (rtc.ok()) (void)rtc.version(&rtcMajor, &rtcMinor);
   char name[64];
   snprintf(name, sizeof name, "%016llx",
            (unsigned long long)fnv1a(src, fnv1a(defines + "|" + key + "|" DNAS_ARCH "|hiprtc" + std::to_string(rtcMajor) + "." + std::to_string(rtcMinor))));
@@ -141,23 +178,24 @@ std::vector<char> jitCompile(const std::string& defines, const std::string& key)
   }
   std::vector<const char*> copts;
   for (const auto& o : opts) copts.push_back(o.c_str());
+  if (!rtc.ok()) throw std::runtime_error("the run-time compiler (libhiprtc.so.7) could not be loaded: no code object for this machine in " + cacheDir);
   hiprtcProgram prog;
-  if (hiprtcCreateProgram(&prog, src.c_str(), "viterbi_tiera.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+  if (rtc.create(&prog, src.c_str(), "viterbi_tiera.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
     throw std::runtime_error("hiprtcCreateProgram failed");
-  const hiprtcResult rc = hiprtcCompileProgram(prog, (int)copts.size(), copts.data());
+  const hiprtcResult rc = rtc.compile(prog, (int)copts.size(), copts.data());
   if (rc != HIPRTC_SUCCESS) {
     size_t n = 0;
-    hiprtcGetProgramLogSize(prog, &n);
+    rtc.logSize(prog, &n);
     std::string log(n, '\0');
-    if (n) hiprtcGetProgramLog(prog, &log[0]);
-    hiprtcDestroyProgram(&prog);
-    throw std::runtime_error(std::string("hiprtc: ") + hiprtcGetErrorString(rc) + "\n" + log);
+    if (n) rtc.log(prog, &log[0]);
+    rtc.destroy(&prog);
+    throw std::runtime_error(std::string("hiprtc: ") + rtc.errorString(rc) + "\n" + log);
   }
   size_t n = 0;
-  hiprtcGetCodeSize(prog, &n);
+  rtc.codeSize(prog, &n);
   std::vector<char> code(n);
-  hiprtcGetCode(prog, code.data());
-  hiprtcDestroyProgram(&prog);
+  rtc.code(prog, code.data());
+  rtc.destroy(&prog);
   // best-effort cache write (atomic rename; a read-only tree just skips it)
   mkdir(cacheDir.c_str(), 0755);
   const std::string tmp = tempName(cachePath);
