@@ -643,9 +643,6 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
           bool grew = d != Dv[k];
           if constexpr (sFed) grew = grew || s != S[k];
           if (grew) {
-#ifdef DNAS_PRIO
-            __builtin_amdgcn_s_setprio(DNAS_PRIO);     // (experiment: a wave with a grown row is on some chain of offers)
-#endif
             changed = 1;
             s = dmax(s, d + a.delEnd);                                 // viterbi.cpp:114-115
             S[k] = s;
@@ -701,9 +698,6 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
                 }
               }
             });
-#ifdef DNAS_PRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
           }
         };
         static_for<0, K>([&](auto kc) {
