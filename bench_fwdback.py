@@ -1,7 +1,7 @@
 """bench.py --config 4: the forward-backward E-step (expectedCounts, reference src/fwdback.cpp:190-209) over synthetic
 (original, read) pairs -- BASELINE configs[4], SURVEY 8(d) "Config 5": originals of 256 random nt, reads with tandem
 duplications (length 1-3, rate .01), substitutions (.02) and deletions (.01), the true alignment as the guide, the CLI
-default error model (P = 6).  125 000 pairs per GPU by default (1M over 8 GPUs); `--unique` distinct synthetic pairs
+default error model (P = 6).  125 000 pairs per GPU by default (1M over 8 GPUs); 16 000 distinct synthetic pairs
 are tiled to that number (making a million alignments in Python would take longer than the measurement).
 
 A "step" is one E-step over the shard with the database resident in HBM (dnas_fb handle: table and pairs uploaded
@@ -51,7 +51,7 @@ def fwdback_line(ctx, n_pairs, steps, warmup, cpu_seconds, timed_only):
     rank, world, local_rank, coll_device = ctx.rank, ctx.world, ctx.local_rank, ctx.coll_device
 
     n_pairs = n_pairs or 125000
-    unique = 2000
+    unique = 16000      # distinct synthetic pairs (42 MB of sequences and guide columns: more than the chip's L2), tiled to n_pairs
     pairs = make_pairs(O, rank * n_pairs, n_pairs, unique)
     pk = O.pack_pairs(pairs)
     nt = int(pk["out_off"][-1])

@@ -136,3 +136,51 @@ def test_one_long_pair_does_not_fail_the_database(oracle_mod):
     oc, oll, oper = O.expected_counts(O.MutatorParams.from_cli(), pairs)
     assert np.array_equal(per, oper) and np.allclose(counts, oc, rtol=1e-9, atol=1e-300)
     fb.close()
+
+
+def test_half_width_wavefront_is_chosen_per_pair(da, oracle_mod, monkeypatch):
+    """The wavefront kernels run a pair on HALF as many lanes as its widest envelope row has cells when every lane has left its row
+    before its next one comes up (hi(ip) - lo(ip + W) < W: alignments that run down a diagonal).  A block of deleted input bases
+    breaks that -- the rows below it all start at the same column --: such pairs must take the full-width kernel, and both kinds
+    give the oracle's numbers, whatever the routing (DNAS_FB_NO_NARROW: nobody takes the half-width kernels)."""
+    from synth import synthetic_alignment
+    O = oracle_mod
+    rng = random.Random(77)
+    rows = [synthetic_alignment(rng, 256) for _ in range(120)]
+    for i in range(40):                          # 24 input bases in a row deleted somewhere in the middle
+        src = "".join(rng.choice("ACGT") for _ in range(200))
+        cut = rng.randrange(40, 120)
+        rows.append([("in", src), ("out", src[:cut] + "-" * 24 + src[cut + 24:])])
+    pairs = [O.alignment_pair(r) for r in rows]
+    pk = O.pack_pairs(pairs)
+    flags = dict(sub=.02, dup=.01, del_open=.02, length=12)
+    oc, oll, oper = O.expected_counts(O.MutatorParams.from_cli(**flags), pairs)
+    stats = []
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("DNAS_FB_NO_NARROW", env)
+        fb = da.ForwardBackward(pk)
+        counts, ll, per = fb.expectedCounts(da.MutatorParams.fromFlags(**flags))
+        stats.append(fb.stats())
+        fb.close()
+        assert np.array_equal(per, oper) and _close(counts, oc)
+    assert stats[0]["pairs_narrow"] >= 100 and stats[0]["pairs_narrow"] <= stats[0]["pairs_onchip"] - 30, stats[0]   # the 40 gapped pairs: full width
+    assert stats[1]["pairs_narrow"] == 0 and stats[1]["pairs_onchip"] == stats[0]["pairs_onchip"]
+
+
+def test_database_checks_run_on_the_gpu(da, oracle_mod):
+    """dnas_fb_load_pairs checks every base and guide column on the device: a bad base and a decreasing guide column are refused."""
+    from synth import synthetic_alignment
+    O = oracle_mod
+    rng = random.Random(5)
+    pairs = [O.alignment_pair(synthetic_alignment(rng, 60)) for _ in range(20)]
+    pk = O.pack_pairs(pairs)
+    bad = dict(pk); bad["outs"] = pk["outs"].copy(); bad["outs"][7] = 4
+    with pytest.raises(da.DnasError, match="DNAS_E_BAD_BASE"):
+        da.ForwardBackward(bad)
+    bad = dict(pk); bad["cm_in"] = pk["cm_in"].copy(); bad["cm_in"][5] = bad["cm_in"][4] - 1
+    with pytest.raises(da.DnasError, match="non-decreasing"):
+        da.ForwardBackward(bad)
+    fb = da.ForwardBackward(pk)                  # ... and the handle API still loads a good database afterwards
+    assert np.array_equal(fb.expectedCounts(da.MutatorParams.fromFlags())[2], O.expected_counts(O.MutatorParams.from_cli(), pairs)[2])
+    fb.close()

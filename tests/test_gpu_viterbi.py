@@ -333,3 +333,17 @@ def test_row_program_autotune(da, oracle_mod, ref_data, tmp_path, monkeypatch):
     assert a[0] == b[0] == c[0] and np.array_equal(a[1].view(np.uint64), b[1].view(np.uint64)) and np.array_equal(a[1].view(np.uint64), c[1].view(np.uint64))
     for d in [shipped] + forced:
         d.close()
+
+
+def test_packed_host_arrays_entry_point(da, oracle_mod, ref_data):
+    """decode_packed = dnas_viterbi_batch on packed host arrays, results as arrays (what a C caller sees, and what bench.py times as
+    the PCIe-inclusive rate): the same strings, log-likelihood bits and status as decode()."""
+    m = da.Machine.fromFile(os.path.join(ref_data, "h74l4c4.json"))
+    dec = da.ViterbiDecoder(m, da.MutatorParams.fromFlags(global_=True))
+    reads = [m.encodeBytes(bytes([i, 3 * i % 256, 255 - i])) for i in range(9)] + [""]
+    out, ll, st = dec.decode(reads)
+    off, bases = da.pack_reads(reads)
+    sym, ooff, olen, ll2, st2 = dec.decode_packed(off, bases)
+    assert [sym[int(ooff[i]):int(ooff[i]) + int(olen[i])].tobytes().decode() for i in range(len(reads))] == out
+    assert np.array_equal(ll2.view(np.uint64), ll.view(np.uint64)) and np.array_equal(st2, st)
+    dec.close()
