@@ -431,9 +431,7 @@ class ForwardBackward:
     def load(self, pairs):
         """dnas_fb_load_pairs: the database goes to the GPU (replacing the one that was there)."""
         pk = pairs.arrays() if isinstance(pairs, StockholmDB) else pairs
-        ptrs = pk.get("_ptrs") if isinstance(pk, dict) else None
-        if ptrs is None:
-            keep, ptrs = _pair_ptrs(pk)
+        keep, ptrs = _pair_ptrs(pk)          # (keep: the arrays must outlive the call)
         self.n = int(pk["n"])
         _l.check(_l.lib().dnas_fb_load_pairs(self._h, self.n, *ptrs))
 

@@ -53,7 +53,7 @@ struct Hiprtc {
     const char* names[] = {getenv("DNAS_HIPRTC_LIBRARY"), "/opt/rocm/lib/libhiprtc.so.7", "libhiprtc.so.7", "libhiprtc.so"};
     for (const char* n : names) {
       if (!n || !*n) continue;
-      if ((lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND))) { where = n; break; }
+      if ((lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) { where = n; break; }
     }
     if (!lib) return;
 #define DNAS_RTC_SYM(field, name) field = reinterpret_cast<decltype(field)>(dlsym(lib, name))
