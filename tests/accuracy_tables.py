@@ -12,9 +12,11 @@ rows of it on the GPU path.  What is restated, with the lines it follows:
     (errdecode.pl:229-231 with -exacterrs; delext = 2 / maxdelsize = 0.2, :109; `--length 4` -> P = 2), control symbols
     stripped (:233), Levenshtein distance to the payload / 8192 (:242-244)
 
-The published table trained its error model per row (`--fit-error` on ten simulated alignments, errdecode.pl:183-203) instead of
-being told the rates; the two agree where the table is decisive: no edits at all up to a substitution rate of 0.004, and
-about one edit per thousand bits at 0.128."""
+The published tables trained their error model per row (`--fit-error --error-global` on ten simulated alignments of 8192 random
+bases, the fitted model written as JSON and read back with `--error-file`: errdecode.pl:183-203, doc/Makefile:127 `-trainalign 10`)
+instead of being told the rates.  fit_model() below does exactly that through the GPU Baum-Welch path; make_case() / the
+`exact` model is the script's `-exacterrs` variant.  Deletions (doc/len4.ham.dels.tab): round(rate * len) draws of a segment of
+1..10 bases at a random place, removed (errdecode.pl:265-293, 301-305; -maxdelsize 10, :32)."""
 import random
 
 import numpy as np
@@ -82,3 +84,60 @@ def edit_distance(a, b):
         if d <= band:
             return d
         band *= 2
+
+
+# ---- deletions, training alignments, the fitted model -----------------------------------------------------------------------
+
+def delete(rng, seq_cols, rate, maxsize=10):
+    """seq_cols: list of (original index or None, base) of the current sequence; round(rate * len) draws of a segment of 1..maxsize
+    bases at a random place, removed (errdecode.pl evolve / randcoords / del)."""
+    n = int(round(rate * len(seq_cols)))
+    for _ in range(n):
+        ln = len(seq_cols)
+        if ln == 0:
+            break
+        size = int(rng.random() * (min(ln, maxsize) + 1 - 1)) + 1
+        pos = int(rng.random() * (ln + 1 - size))
+        del seq_cols[pos:pos + size]
+    return seq_cols
+
+
+def evolve(rng, dna, sub_rate, del_rate, ivratio=10.0):
+    """substitutions then deletions, as errdecode.pl applies them (:214-216) -> (read, alignment rows (original, read) with gaps)"""
+    seq = list(substitute(rng, dna, sub_rate, ivratio)) if sub_rate > 0 else list(dna)
+    cols = delete(rng, list(enumerate(seq)), del_rate) if del_rate > 0 else list(enumerate(seq))
+    kept = {i: b for i, b in cols}
+    read = "".join(b for _, b in cols)
+    return read, (dna, "".join(kept.get(i, "-") for i in range(len(dna))))
+
+
+def make_case_general(machine, sub_rate, del_rate, rep, tag, bits=BITS):
+    rng = random.Random("%s %r %r %d" % (tag, sub_rate, del_rate, rep))
+    payload = "".join(rng.choice("01") for _ in range(bits))
+    read, _ = evolve(rng, machine.encodeSymbols(payload), sub_rate, del_rate)
+    return payload, read
+
+
+def training_stockholm(sub_rate, del_rate, tag, n=10, length=BITS):
+    """ten alignments of a random sequence of 8192 bases and its mutated copy (errdecode.pl:187-199), as Stockholm text"""
+    out = []
+    for k in range(n):
+        rng = random.Random("train %s %r %r %d" % (tag, sub_rate, del_rate, k))
+        orig = "".join(rng.choice("ACGT") for _ in range(length))
+        _, (row_old, row_new) = evolve(rng, orig, sub_rate, del_rate)
+        out.append("# STOCKHOLM 1.0\nold %s\nnew %s\n//\n" % (row_old, row_new))
+    return "".join(out)
+
+
+def fit_model(da, sub_rate, del_rate, tag, workdir):
+    """`dnastore --length 4 --fit-error train.stk --error-global` (errdecode.pl:201), the printed JSON read back as --error-file:
+    -> (MutatorParams as the decoder loads them, the JSON text, Baum-Welch iterations)"""
+    import os
+    stk = os.path.join(workdir, "train.%s.stk" % tag)
+    open(stk, "w").write(training_stockholm(sub_rate, del_rate, tag))
+    init = da.MutatorParams.fromFlags(global_=True, length=4)          # the CLI's defaults otherwise (t/dnastore.cpp:115-130)
+    fit, iters = da.baumWelchParams(init, da.StockholmDB(stk))
+    text = da.paramsJSON(fit)
+    err = os.path.join(workdir, "fit.%s.err.json" % tag)
+    open(err, "w").write(text)
+    return da.MutatorParams.fromFile(err), text, iters
