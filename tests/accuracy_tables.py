@@ -15,8 +15,11 @@ rows of it on the GPU path.  What is restated, with the lines it follows:
 The published tables trained their error model per row (`--fit-error --error-global` on ten simulated alignments of 8192 random
 bases, the fitted model written as JSON and read back with `--error-file`: errdecode.pl:183-203, doc/Makefile:127 `-trainalign 10`)
 instead of being told the rates.  fit_model() below does exactly that through the GPU Baum-Welch path; make_case() / the
-`exact` model is the script's `-exacterrs` variant.  Deletions (doc/len4.ham.dels.tab): round(rate * len) draws of a segment of
-1..10 bases at a random place, removed (errdecode.pl:265-293, 301-305; -maxdelsize 10, :32)."""
+`exact` model is the script's `-exacterrs` variant.  Deletions (doc/len4*.dels.tab): round(rate * len) draws of a segment of
+1..10 bases at a random place, removed (errdecode.pl:265-293, 301-305; -maxdelsize 10, :32); tandem duplications
+(doc/len4.mix2.dups.tab): segments of 1..4 bases copied in place, no overlaps (:31, 295-299).  The machines: `--length 4
+--controls 4` alone (data/l4c4.json: len4.*.tab), composed with mixradar2.json (mr2l4c4.json: len4.mix2.*.tab) or with
+hamming74.json (h74l4c4.json: len4.ham.*.tab) -- errdecode.pl:151-176, doc/Makefile:129-153."""
 import random
 
 import numpy as np
@@ -102,42 +105,86 @@ def delete(rng, seq_cols, rate, maxsize=10):
     return seq_cols
 
 
-def evolve(rng, dna, sub_rate, del_rate, ivratio=10.0):
-    """substitutions then deletions, as errdecode.pl applies them (:214-216) -> (read, alignment rows (original, read) with gaps)"""
-    seq = list(substitute(rng, dna, sub_rate, ivratio)) if sub_rate > 0 else list(dna)
-    cols = delete(rng, list(enumerate(seq)), del_rate) if del_rate > 0 else list(enumerate(seq))
-    kept = {i: b for i, b in cols}
-    read = "".join(b for _, b in cols)
-    return read, (dna, "".join(kept.get(i, "-") for i in range(len(dna))))
+def duplicate(rng, cols, rate, maxsize=4):
+    """cols: list of [original index or None, base, mutated]; round(rate * len) draws of a segment of 1..maxsize bases; a segment
+    that touches an earlier duplication's copy is skipped (no overlaps: errdecode.pl:270-273, :31), else its copy is inserted
+    right behind it (errdecode.pl dup, :295-299)"""
+    n = int(round(rate * len(cols)))
+    for _ in range(n):
+        ln = len(cols)
+        size = int(rng.random() * (min(ln, maxsize) + 1 - 1)) + 1
+        pos = int(rng.random() * (ln + 1 - size))
+        seg = cols[pos:pos + size]
+        if any(c[2] for c in seg):
+            continue
+        cols[pos + size:pos + size] = [[None, c[1], True] for c in seg]
+    return cols
 
 
-def make_case_general(machine, sub_rate, del_rate, rep, tag, bits=BITS):
-    rng = random.Random("%s %r %r %d" % (tag, sub_rate, del_rate, rep))
+def evolve(rng, dna, sub_rate, del_rate, dup_rate=0.0, ivratio=10.0):
+    """duplications, then substitutions, then deletions, as errdecode.pl applies them (:214-216)
+    -> (read, alignment rows (original, read) with gaps)"""
+    cols = [[i, b, False] for i, b in enumerate(dna)]
+    if dup_rate > 0:
+        cols = duplicate(rng, cols, dup_rate)
+    if sub_rate > 0:
+        for _ in range(int(round(sub_rate * len(cols)))):
+            pos = int(rng.random() * len(cols))
+            base = cols[pos][1]
+            cols[pos][1] = TRANSVERSION[base][int(rng.random() * 2)] if rng.random() < 1.0 / (1.0 + ivratio) else TRANSITION[base]
+            cols[pos][2] = True
+    if del_rate > 0:
+        cols = delete(rng, cols, del_rate)
+    read = "".join(c[1] for c in cols)
+    # alignment: walk the original; read-only columns (copies) go where they stand
+    row_old, row_new, nxt = [], [], 0
+    for c in cols:
+        if c[0] is None:
+            row_old.append("-"); row_new.append(c[1])
+            continue
+        while nxt < c[0]:
+            row_old.append(dna[nxt]); row_new.append("-"); nxt += 1
+        row_old.append(dna[c[0]]); row_new.append(c[1]); nxt = c[0] + 1
+    while nxt < len(dna):
+        row_old.append(dna[nxt]); row_new.append("-"); nxt += 1
+    return read, ("".join(row_old), "".join(row_new))
+
+
+def make_case_general(machine, sub_rate, del_rate, rep, tag, bits=BITS, dup_rate=0.0):
+    rng = random.Random("%s %r %r %r %d" % (tag, sub_rate, del_rate, dup_rate, rep) if dup_rate else "%s %r %r %d" % (tag, sub_rate, del_rate, rep))
     payload = "".join(rng.choice("01") for _ in range(bits))
-    read, _ = evolve(rng, machine.encodeSymbols(payload), sub_rate, del_rate)
+    read, _ = evolve(rng, machine.encodeSymbols(payload), sub_rate, del_rate, dup_rate)
     return payload, read
 
 
-def training_stockholm(sub_rate, del_rate, tag, n=10, length=BITS):
+def training_stockholm(sub_rate, del_rate, tag, n=10, length=BITS, dup_rate=0.0):
     """ten alignments of a random sequence of 8192 bases and its mutated copy (errdecode.pl:187-199), as Stockholm text"""
     out = []
     for k in range(n):
-        rng = random.Random("train %s %r %r %d" % (tag, sub_rate, del_rate, k))
+        rng = random.Random("train %s %r %r %r %d" % (tag, sub_rate, del_rate, dup_rate, k) if dup_rate else "train %s %r %r %d" % (tag, sub_rate, del_rate, k))
         orig = "".join(rng.choice("ACGT") for _ in range(length))
-        _, (row_old, row_new) = evolve(rng, orig, sub_rate, del_rate)
+        _, (row_old, row_new) = evolve(rng, orig, sub_rate, del_rate, dup_rate)
         out.append("# STOCKHOLM 1.0\nold %s\nnew %s\n//\n" % (row_old, row_new))
     return "".join(out)
 
 
-def fit_model(da, sub_rate, del_rate, tag, workdir):
+def fit_model(da, sub_rate, del_rate, tag, workdir, dup_rate=0.0):
     """`dnastore --length 4 --fit-error train.stk --error-global` (errdecode.pl:201), the printed JSON read back as --error-file:
     -> (MutatorParams as the decoder loads them, the JSON text, Baum-Welch iterations)"""
     import os
     stk = os.path.join(workdir, "train.%s.stk" % tag)
-    open(stk, "w").write(training_stockholm(sub_rate, del_rate, tag))
+    open(stk, "w").write(training_stockholm(sub_rate, del_rate, tag, dup_rate=dup_rate))
     init = da.MutatorParams.fromFlags(global_=True, length=4)          # the CLI's defaults otherwise (t/dnastore.cpp:115-130)
     fit, iters = da.baumWelchParams(init, da.StockholmDB(stk))
     text = da.paramsJSON(fit)
     err = os.path.join(workdir, "fit.%s.err.json" % tag)
     open(err, "w").write(text)
     return da.MutatorParams.fromFile(err), text, iters
+
+
+MACHINE_OF_TABLE = {"len4": "l4c4.json", "len4.mix2": "mr2l4c4.json", "len4.ham": "h74l4c4.json"}
+
+
+def machine_file(table_stem):
+    """'len4.mix2.dups' -> 'mr2l4c4.json'"""
+    return MACHINE_OF_TABLE[table_stem.rsplit(".", 1)[0]]
