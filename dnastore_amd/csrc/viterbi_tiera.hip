@@ -879,8 +879,8 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
         const unsigned pv = G_ > 1 ? opaque(pairValid) : ~0u;
         static_for<1, D_>([&](auto ic) {
           constexpr int i = ic.value;
-          // (in the first columns of a read the history is shorter than D - 1: nobody
-          //  uses what they bring (column pos - i < 1 does not exist: they fetch column pos instead) -- unconditional, so that a slot of the ring is dead from its last use to its next load)
+          // (unconditional loads, so that a slot of the ring is dead from its last use to its next load: in the first columns of a
+          //  read, where column pos - i does not exist, they fetch column pos instead and nobody uses what they bring)
           const int colH = pos - i >= 1 ? pos - i : pos;
           static_for<p0, p1>([&](auto mc) {
             constexpr int m2 = mc.value;
