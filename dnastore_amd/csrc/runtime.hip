@@ -529,8 +529,9 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
                 hipMemcpy(m->dFoldTab, p.foldTab.data(), p.foldTab.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
               throw std::runtime_error("tier C exchange buffer allocation failed");
             // watchdog per lattice column.  A column takes tens of microseconds, but the clock keeps running while the device's
-            // scheduler lets another queue's kernel run (two cluster launches at once on one card were seen to stall each other
-            // for 2-6 s at a time): the limit only has to turn a protocol failure into an error instead of a hung GPU
+            // scheduler lets another queue's kernel run: the limit only has to turn a protocol failure into an error instead
+            // of a hung GPU.  (Two cluster launches at once on one card take turns launch by launch; the stalls of 2-6 s once
+            // seen beside them were hipMalloc / hipFree of the arenas: tools/alloc_probe.py)
             double seconds = 30.0;
             if (const char* s = opt("cluster_timeout_s")) seconds = std::max(0.001, atof(s));
             m->timeoutTicks = (unsigned long long)(seconds * 1e8);   // s_memrealtime counts at 100 MHz
