@@ -23,7 +23,7 @@ w = list(w)
 cols = len(reads[0]) + 1
 tot = sum(w[1:5])
 print("stats", s)
-print("block0: cycles/col  A %.0f  publish %.0f  sweeps %.0f  C %.0f  (total %.0f = %.1f us @100MHz ticks?)  rounds/col %.1f" % (
-    w[1] / cols, w[2] / cols, w[3] / cols, w[4] / cols, tot / cols, tot / cols / 100.0, w[5] / cols))
+print("block0: cycles/col  A %.0f  publish %.0f  sweeps %.0f  C %.0f  (total %.0f)  rounds/col %.1f  extra stamp %.0f" % (
+    w[1] / cols, w[2] / cols, w[3] / cols, w[4] / cols, tot / cols, w[5] / cols, w[6] / cols))
 print("shares: A %.1f%% P %.1f%% B %.1f%% C %.1f%%; cycles per sweep %.0f" % (100*w[1]/tot, 100*w[2]/tot, 100*w[3]/tot, 100*w[4]/tot, w[3]/max(w[5],1)))
 print("fill_ms %.2f -> %.1f us/col" % (s["fill_ms"], s["fill_ms"] * 1e3 / cols))
