@@ -51,6 +51,11 @@ def main():
         digests.add(digest(strings, ll))
     print(json.dumps({"walls_s": walls, "fill_ms": fills, "digests": sorted(digests), "tier": dec.tier,
                       "t_first": t0 - sum(walls[:-1]), "t_last": time.time()}), flush=True)
+    # the arena goes back only when the other process is through as well: hipFree of tens of GB stalls whoever else talks to
+    # the driver at that moment (tools/alloc_probe.py)
+    deadline = time.time() + 120
+    while not os.path.exists(start_file + ".done") and time.time() < deadline:
+        time.sleep(0.01)
     dec.close()
 
 

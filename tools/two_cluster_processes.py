@@ -29,12 +29,15 @@ def run_pair(options, calls, timeout=300):
                 raise RuntimeError("a child did not come up: " + " | ".join(p.communicate()[1][-2000:] for p in procs))
             time.sleep(0.01)
         open(start, "w").close()
+        # a child prints its line when its calls are through and keeps its arena until both are (the ".done" file)
+        lines = [p.stdout.readline() for p in procs]
+        open(start + ".done", "w").close()
         out = []
-        for p in procs:
+        for p, line in zip(procs, lines):
             so, se = p.communicate(timeout=timeout)
-            if p.returncode != 0:
-                raise RuntimeError("child failed: " + se[-2000:])
-            out.append(json.loads(so.strip().splitlines()[-1]))
+            if p.returncode != 0 or not line.strip():
+                raise RuntimeError("child failed (exit %s): %s" % (p.returncode, se[-2000:]))
+            out.append(json.loads(line))
         return out
 
 
