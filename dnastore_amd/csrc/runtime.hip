@@ -125,7 +125,11 @@ struct dnas_model {
   std::vector<int64_t> lastBatchStart; // first read (sorted order) of every batch of the last call, + n_reads
   std::vector<uint64_t> lastReadOff;   // host copy of the last call's read offsets
   const uint8_t* lastBases = nullptr;  // device pointer of the last call's bases (valid while the caller keeps it)
-  uint8_t* keepBases = nullptr;        // dnas_viterbi_batch's own copy, kept until the next call (lattice export)
+  // dnas_viterbi_batch's device copies of the caller's host arrays: owned by the model and only ever grown (hipMalloc / hipFree
+  // per call is what another tenant of the card can hold up for seconds: tools/alloc_probe.py); the bases stay valid until the
+  // next call (lattice export)
+  uint8_t* ioBases = nullptr; char* ioSym = nullptr; uint32_t* ioLen = nullptr; double* ioLL = nullptr; uint8_t* ioSt = nullptr;
+  size_t ioBasesCap = 0, ioSymCap = 0, ioReadsCap = 0;
   std::vector<hipEvent_t> events;      // 4 per batch: fill start/end (stream), traceback start/end (stream2)
   dnas_batch_stats stats{};
   bool statsPending = false;
@@ -605,7 +609,11 @@ extern "C" void dnas_model_destroy(dnas_model* m) {
   for (void* p : m->owned) (void)hipFree(p);
   if (m->arena) (void)hipFree(m->arena);
   if (m->dRounds) (void)hipFree(m->dRounds);
-  if (m->keepBases) (void)hipFree(m->keepBases);
+  if (m->ioBases) (void)hipFree(m->ioBases);
+  if (m->ioSym) (void)hipFree(m->ioSym);
+  if (m->ioLen) (void)hipFree(m->ioLen);
+  if (m->ioLL) (void)hipFree(m->ioLL);
+  if (m->ioSt) (void)hipFree(m->ioSt);
   if (m->dEntTab) (void)hipFree(m->dEntTab);
   if (m->dMetaTab) (void)hipFree(m->dMetaTab);
   if (m->dSlotOf) (void)hipFree(m->dSlotOf);
@@ -1097,39 +1105,37 @@ extern "C" int dnas_viterbi_batch(dnas_model* m, int64_t n_reads, const uint64_t
   for (size_t i = 0; i < nBases; ++i)
     if (bases[i] > 3) return dnas::fail(DNAS_E_BAD_BASE, "base code > 3 at offset " + std::to_string(i));
   const size_t nOut = (size_t)out_offsets[n_reads];
-  if (m->keepBases) { (void)hipFree(m->keepBases); m->keepBases = nullptr; m->lastBases = nullptr; }
-  uint8_t* dBases = nullptr; char* dSym = nullptr; uint32_t* dLen = nullptr; double* dLL = nullptr; uint8_t* dSt = nullptr;
-  int rc = DNAS_OK;
-  bool keep = false;
-  auto cleanup = [&]() {
-    if (dBases && !keep) (void)hipFree(dBases);
-    if (dSym) (void)hipFree(dSym);
-    if (dLen) (void)hipFree(dLen);
-    if (dLL) (void)hipFree(dLL);
-    if (dSt) (void)hipFree(dSt);
+  // (the streams are idle: the call before was synchronised before it returned its results)
+  auto grow = [&](void** p, size_t* cap, size_t need, size_t elem) -> int {
+    if (need <= *cap && *p) return DNAS_OK;
+    if (*p) HIP_TRY(hipFree(*p));
+    *p = nullptr; *cap = 0;
+    const size_t want = std::max<size_t>(need + need / 4, 256);
+    HIP_TRY(hipMalloc(p, want * elem));
+    *cap = want;
+    return DNAS_OK;
   };
-#define TRY_OR_CLEAN(expr)                                                                                        \
-  do {                                                                                                            \
-    hipError_t e_ = (expr);                                                                                       \
-    if (e_ != hipSuccess) { cleanup(); return dnas::fail(DNAS_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } \
-  } while (0)
-  TRY_OR_CLEAN(hipMalloc((void**)&dBases, std::max<size_t>(nBases, 1)));
-  TRY_OR_CLEAN(hipMalloc((void**)&dSym, std::max<size_t>(nOut, 1)));
-  TRY_OR_CLEAN(hipMalloc((void**)&dLen, (size_t)n_reads * sizeof(uint32_t)));
-  TRY_OR_CLEAN(hipMalloc((void**)&dLL, (size_t)n_reads * sizeof(double)));
-  TRY_OR_CLEAN(hipMalloc((void**)&dSt, (size_t)n_reads));
-  if (nBases) TRY_OR_CLEAN(hipMemcpy(dBases, bases, nBases, hipMemcpyHostToDevice));
-  rc = dnas_viterbi_batch_device(m, n_reads, read_offsets, dBases, dSym, out_offsets, dLen, dLL, dSt);
+  int rc;
+  m->lastBases = nullptr;
+  if ((rc = grow((void**)&m->ioBases, &m->ioBasesCap, nBases, 1)) != DNAS_OK) return rc;
+  if ((rc = grow((void**)&m->ioSym, &m->ioSymCap, nOut, 1)) != DNAS_OK) return rc;
+  if ((size_t)n_reads > m->ioReadsCap || !m->ioLen) {
+    if (m->ioLen) { (void)hipFree(m->ioLen); (void)hipFree(m->ioLL); (void)hipFree(m->ioSt); }
+    m->ioLen = nullptr; m->ioLL = nullptr; m->ioSt = nullptr; m->ioReadsCap = 0;
+    const size_t want = (size_t)n_reads + (size_t)n_reads / 4 + 64;
+    HIP_TRY(hipMalloc((void**)&m->ioLen, want * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&m->ioLL, want * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&m->ioSt, want));
+    m->ioReadsCap = want;
+  }
+  if (nBases) HIP_TRY(hipMemcpy(m->ioBases, bases, nBases, hipMemcpyHostToDevice));
+  rc = dnas_viterbi_batch_device(m, n_reads, read_offsets, m->ioBases, m->ioSym, out_offsets, m->ioLen, m->ioLL, m->ioSt);
   if (rc == DNAS_OK) rc = dnas_model_sync(m);
-  if (rc != DNAS_OK) { cleanup(); return rc; }
-  if (nOut) TRY_OR_CLEAN(hipMemcpy(out_sym, dSym, nOut, hipMemcpyDeviceToHost));
-  TRY_OR_CLEAN(hipMemcpy(out_len, dLen, (size_t)n_reads * sizeof(uint32_t), hipMemcpyDeviceToHost));
-  TRY_OR_CLEAN(hipMemcpy(out_loglike, dLL, (size_t)n_reads * sizeof(double), hipMemcpyDeviceToHost));
-  TRY_OR_CLEAN(hipMemcpy(out_status, dSt, (size_t)n_reads, hipMemcpyDeviceToHost));
-#undef TRY_OR_CLEAN
-  keep = true;
-  m->keepBases = dBases;
-  cleanup();
+  if (rc != DNAS_OK) return rc;
+  if (nOut) HIP_TRY(hipMemcpy(out_sym, m->ioSym, nOut, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out_len, m->ioLen, (size_t)n_reads * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out_loglike, m->ioLL, (size_t)n_reads * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out_status, m->ioSt, (size_t)n_reads, hipMemcpyDeviceToHost));
   return DNAS_OK;
 }
 
