@@ -417,6 +417,44 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
     for (int e = 0; e < fm->n_null; ++e) ns[(size_t)e] = slotOf ? slotOf[fm->nin_src[e]] : fm->nin_src[e];
     int r = upload(m, es.data(), es.size(), &d.einSlot);
     if (r == DNAS_OK) r = upload(m, ns.data(), ns.size(), &d.ninSlot);
+    if (r != DNAS_OK) return r;
+    // node records (device_model.h): only when the machine's edge scores are few enough to be named by a byte
+    d.rec = nullptr; d.recScore = nullptr;
+    if (D > 4 || getenv("DNAS_NO_NODE_RECORDS")) return DNAS_OK;
+    std::vector<double> scores;
+    auto scoreIndex = [&](double v) -> int {
+      for (size_t i = 0; i < scores.size(); ++i) if (memcmp(&scores[i], &v, sizeof v) == 0) return (int)i;
+      if (scores.size() >= 256) return -1;
+      scores.push_back(v);
+      return (int)scores.size() - 1;
+    };
+    std::vector<uint32_t> rec((size_t)N * 16, 0u);
+    for (int j = 0; j < N; ++j) {
+      uint32_t* w = &rec[(size_t)j * 16];
+      const int e0 = fm->ein_ptr[j], ne = fm->ein_ptr[j + 1] - e0, n0 = fm->nin_ptr[j], nn = fm->nin_ptr[j + 1] - n0;
+      uint32_t ctxBits = 0;
+      for (int q = 0; q < D; ++q) ctxBits |= (uint32_t)(fm->ctx[(size_t)j * D + q] & 3u) << (2 * q);
+      w[0] = (uint32_t)(ne > kRecEmit ? 15 : ne) | (uint32_t)(nn > kRecNull ? 15 : nn) << 4 | (uint32_t)fm->mdl[j] << 8 | ctxBits << 12;
+      w[1] = (uint32_t)(slotOf ? slotOf[j] : j);
+      for (int i = 0; i < ne && ne <= kRecEmit; ++i) {
+        const int k = scoreIndex(fm->ein_score[e0 + i]);
+        if (k < 0) return DNAS_OK;
+        w[2 + 3 * i] = (uint32_t)fm->ein_src[e0 + i];
+        w[3 + 3 * i] = (uint32_t)es[(size_t)(e0 + i)];
+        w[4 + 3 * i] = (uint32_t)fm->ein_in[e0 + i] | (uint32_t)fm->ein_base[e0 + i] << 8 | (uint32_t)k << 16;
+      }
+      for (int i = 0; i < nn && nn <= kRecNull; ++i) {
+        const int k = scoreIndex(fm->nin_score[n0 + i]);
+        if (k < 0) return DNAS_OK;
+        w[11 + 3 * i] = (uint32_t)fm->nin_src[n0 + i];
+        w[12 + 3 * i] = (uint32_t)ns[(size_t)(n0 + i)];
+        w[13 + 3 * i] = (uint32_t)fm->nin_in[n0 + i] | (uint32_t)k << 16;
+      }
+    }
+    if (scores.empty()) scores.push_back(0.);
+    r = upload(m, scores.data(), scores.size(), &d.recScore);
+    if (r == DNAS_OK) r = upload(m, rec.data(), rec.size(), &d.rec);
+    if (r != DNAS_OK) { d.rec = nullptr; d.recScore = nullptr; }
     return r;
   };
   {
@@ -588,7 +626,7 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
   if (m->tier == 2) m->maxSlots = 1 << 20;   // persistent clusters walk any number of reads: a launch is bounded by the arena only
   if (const char* s = opt("max_slots")) m->maxSlots = std::max(1, atoi(s));
   if (const char* s = opt("traceback")) m->waveTraceback = !(s[0] == 't' || s[0] == 'T');
-  if (const char* s = opt("tb_threads")) m->tbThreads = std::max(64, std::min(1024, atoi(s) / 64 * 64));
+  if (const char* s = opt("tb_threads")) m->tbThreads = std::max(64, std::min(256, atoi(s) / 64 * 64));
   if (const char* s = opt("checkpoint")) m->checkpointMode = (s[0] == 'a' && s[1] == 'l') ? 1 : (s[0] == 'n' ? 2 : 0);   // auto | always | never
   if (const char* s = opt("segment")) m->segmentCols = std::max(0, atoi(s));
   if (const char* s = opt("arena_fraction")) {

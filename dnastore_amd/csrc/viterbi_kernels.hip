@@ -279,13 +279,19 @@ viterbi_fill_kernel(DevModel m, const uint8_t* __restrict__ bases, const uint64_
 
 // One thread per read: the reference's sequential pointer chase, candidate order and
 // strict '>' tie-breaking included (viterbi.cpp:217-228,247-301).
-extern "C" __global__ void __launch_bounds__(1024)
+extern "C" __global__ void __launch_bounds__(256)
 viterbi_traceback_kernel(DevModel m, const uint8_t* __restrict__ bases, const uint64_t* __restrict__ readOff,
                          const int32_t* __restrict__ batchRead, const uint64_t* __restrict__ slotOff,
                          const double* __restrict__ arena, char* __restrict__ outSym,
                          const uint64_t* __restrict__ outOff, uint32_t* __restrict__ outLen,
                          uint8_t* __restrict__ outStatus, int nBatch,
                          unsigned long long* __restrict__ events, const uint64_t* __restrict__ evOff, uint32_t* __restrict__ evLen) {
+  // the model's small tables, indexed per lane: from LDS (a per-lane index into the kernel-argument block is a load from
+  // wherever the runtime keeps kernel arguments -- host memory, as a rule -- in the middle of every step)
+  __shared__ double subT[16], lenT[kMaxLen];
+  if (threadIdx.x < 16) subT[threadIdx.x] = m.sub[threadIdx.x];
+  if (threadIdx.x < kMaxLen) lenT[threadIdx.x] = m.len[threadIdx.x];
+  __syncthreads();
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nBatch) return;
   const int read = batchRead[b];
@@ -343,6 +349,10 @@ viterbi_traceback_kernel(DevModel m, const uint8_t* __restrict__ bases, const ui
     state = bestState; pos = bestPos; mut = bestMut; curCell = bestCell; }
   const int32_t* slotOf = m.slotOf;
 #define SLOT(st) (slotOf ? slotOf[st] : (st))
+  const bool useRec = m.rec != nullptr && ev == nullptr;
+  bool haveRec = false;
+  uint4 cur0 = {0, 0, 0, 0}, cur1 = cur0, cur2 = cur0, cur3 = cur0;   // the node record of `state`
+#define LOAD_REC(dst, st) { const uint4* r_ = (const uint4*)(m.rec + (size_t)(st) * 16); dst##0 = r_[0]; dst##1 = r_[1]; dst##2 = r_[2]; dst##3 = r_[3]; }
 
   do {  // single-pass block so CHECK_BEST can break out on failure
     INIT_BEST();
@@ -359,17 +369,121 @@ viterbi_traceback_kernel(DevModel m, const uint8_t* __restrict__ bases, const ui
     CHECK_BEST();
 
     while (pos >= 0 && state > 0) {
+      INIT_BEST();
+      // ---- the step from the state's node record (device_model.h): the record names the in-edges, so the candidates' cells
+      // are loaded at once -- and with them the RECORDS of the candidate states, one of which is the next step's: a step
+      // costs one memory latency instead of three (row pointers, edge fields, cells).  States with more in-edges than a
+      // record holds, the local start column and the event log take the walk through the CSR arrays below.
+      const int stateWas = state;
+      int adopt = -1;            // fast step taken: 0..3 = the next state's record is pre[adopt], 4 = the state stays
+      if (useRec) {
+        if (!haveRec) { LOAD_REC(cur, state) haveRec = true; }
+        const unsigned hd = cur0.x;
+        const int nE = (int)(hd & 15u), nN = (int)((hd >> 4) & 15u);
+        if (nE != 15 && nN != 15 && !(mut == 0 && pos == 0 && m.local)) {
+          const int mdlR = (int)((hd >> 8) & 15u), ownSlotR = (int)cur0.y;
+          const unsigned ctxR = (hd >> 12) & 0xffu;
+          const size_t strideR = (size_t)m.Npad, SL = (size_t)m.storedLanes;
+          auto LAT = [&](int ps, int ln, int slot) -> double { return lat[((size_t)ps * SL + (size_t)ln) * strideR + (size_t)slot]; };
+          // own duplication lane k at column ps (lattice_cell's chain, the record's context)
+          auto ownT = [&](int ps, int k) -> double {
+            if (SL > 2) return LAT(ps, 2 + k, ownSlotR);
+            if (ps < 1 || k >= mdlR) return kNegInf;
+            int I = mdlR - 1 - k;
+            if (ps - 1 < I) I = ps - 1;
+            // (records exist for D <= 4: at most four S cells, all loaded before the chain is evaluated -- a loop over them
+            //  would wait for every one in turn)
+            double sv[4];
+            int xb[4];
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {
+              sv[i] = i <= I ? LAT(ps - i, 0, ownSlotR) : 0.;
+              xb[i] = i < I ? (int)seq[ps - i - 1] : 0;
+            }
+            double v = kNegInf;
+            _Pragma("unroll") for (int i = 3; i >= 0; --i) {
+              if (i == I) v = (sv[i] + m.tanDup) + lenT[k + i];
+              else if (i < I) v = dmax(v + subT[((ctxR >> (2 * (k + i + 1))) & 3u) * 4 + xb[i]], (sv[i] + m.tanDup) + lenT[k + i]);
+            }
+            return v;
+          };
+          const int eSrc[3] = {(int)cur0.z, (int)cur1.y, (int)cur2.x}, eSlot[3] = {(int)cur0.w, (int)cur1.z, (int)cur2.y};
+          const unsigned eMisc[3] = {cur1.x, cur1.w, cur2.z};
+          const int nSrc = (int)cur2.w, nSlot = (int)cur3.x;
+          const unsigned nMisc = cur3.y;
+          uint4 pre0[4], pre1[4], pre2[4], pre3[4];   // pre<word>[candidate]: the records of the emit sources 0..2 and of the null source
+#define LOAD_PRE(i, st) { const uint4* r_ = (const uint4*)(m.rec + (size_t)(st) * 16); pre0[i] = r_[0]; pre1[i] = r_[1]; pre2[i] = r_[2]; pre3[i] = r_[3]; }
+          // the candidates in the reference's order: value, transition score, (state, pos, lane), input symbol, record to adopt
+#define TAKE(val, trans, st_, ps_, ln_, in_, adopt_) { const double v_ = (val); const double sc_ = v_ + (trans); \
+            if (sc_ > best) { best = sc_; bestCell = v_; bestState = (st_); bestPos = (ps_); bestMut = (ln_); bestIn = (uint8_t)(in_); found = true; adopt = (adopt_); } }
+          if (mut == 0) {
+            const int x = pos > 0 ? seq[pos - 1] : 0;
+            double ve[3], te[3];
+            _Pragma("unroll") for (int i = 0; i < 3; ++i) {
+              ve[i] = kNegInf; te[i] = 0.;
+              if (pos > 0 && i < nE) {
+                ve[i] = LAT(pos - 1, 0, eSlot[i]);
+                te[i] = (m.recScore[(eMisc[i] >> 16) & 255u] + m.noGap) + subT[((eMisc[i] >> 8) & 255u) * 4 + x];
+                LOAD_PRE(i, eSrc[i])
+              }
+            }
+            double vn = kNegInf, tn = 0.;
+            if (nN > 0) { vn = LAT(pos, 0, nSlot); tn = m.recScore[(nMisc >> 16) & 255u]; LOAD_PRE(3, nSrc) }
+            const double vd = LAT(pos, 1, ownSlotR);
+            const bool dup = mdlR > 0 && pos > 0;
+            const double vt = dup ? ownT(pos - 1, 0) : kNegInf;
+            _Pragma("unroll") for (int i = 0; i < 3; ++i)
+              if (pos > 0 && i < nE) TAKE(ve[i], te[i], eSrc[i], pos - 1, 0, eMisc[i] & 255u, i)
+            if (nN > 0) TAKE(vn, tn, nSrc, pos, 0, nMisc & 255u, 3)
+            TAKE(vd, m.delEnd, state, pos, 1, 0, 4)
+            if (dup) TAKE(vt, subT[(ctxR & 3u) * 4 + x], state, pos - 1, 2, 0, 4)
+          } else if (mut == 1) {
+            double vD[3], vS[3], sc[3];
+            _Pragma("unroll") for (int i = 0; i < 3; ++i) {
+              vD[i] = vS[i] = kNegInf; sc[i] = 0.;
+              if (i < nE) {
+                vD[i] = LAT(pos, 1, eSlot[i]);
+                vS[i] = LAT(pos, 0, eSlot[i]);
+                sc[i] = m.recScore[(eMisc[i] >> 16) & 255u];
+                LOAD_PRE(i, eSrc[i])
+              }
+            }
+            double vn = kNegInf, tn = 0.;
+            if (nN > 0) { vn = LAT(pos, 1, nSlot); tn = m.recScore[(nMisc >> 16) & 255u]; LOAD_PRE(3, nSrc) }
+            _Pragma("unroll") for (int i = 0; i < 3; ++i)
+              if (i < nE) {
+                TAKE(vD[i], sc[i] + m.delExtend, eSrc[i], pos, 1, eMisc[i] & 255u, i)
+                TAKE(vS[i], sc[i] + m.delOpen, eSrc[i], pos, 0, eMisc[i] & 255u, i)
+              }
+            if (nN > 0) TAKE(vn, tn, nSrc, pos, 1, nMisc & 255u, 3)
+          } else {
+            const int k = mut - 2;
+            const bool deeper = k < mdlR - 1;
+            const double vt = deeper ? ownT(pos - 1, k + 1) : kNegInf;
+            const double vs = LAT(pos, 0, ownSlotR);
+            if (deeper) TAKE(vt, subT[((ctxR >> (2 * (k + 1))) & 3u) * 4 + seq[pos - 1]], state, pos - 1, 2 + k + 1, 0, 4)
+            TAKE(vs, m.tanDup + lenT[k], state, pos, 0, 0, 4)
+            if (adopt < 0) adopt = 4;
+          }
+          if (adopt < 0) adopt = 4;     // no candidate at all: CHECK_BEST below reports it
+          if (adopt == 0) { cur0 = pre0[0]; cur1 = pre1[0]; cur2 = pre2[0]; cur3 = pre3[0]; }
+          else if (adopt == 1) { cur0 = pre0[1]; cur1 = pre1[1]; cur2 = pre2[1]; cur3 = pre3[1]; }
+          else if (adopt == 2) { cur0 = pre0[2]; cur1 = pre1[2]; cur2 = pre2[2]; cur3 = pre3[2]; }
+          else if (adopt == 3) { cur0 = pre0[3]; cur1 = pre1[3]; cur2 = pre2[3]; cur3 = pre3[3]; }
+#undef TAKE
+#undef LOAD_PRE
+        }
+      }
+      if (adopt < 0) {
       const int mdl = m.mdl[state];
       const uint8_t* ctx = m.ctx + (size_t)state * D_;
       const int ownSlot = SLOT(state);
-      INIT_BEST();
       if (mut == 0) {
         if (pos > 0) {
           const int x = seq[pos - 1];
           const int e1 = m.einPtr[state + 1];
           for (int e0 = m.einPtr[state]; e0 < e1; e0 += CH) {
             _Pragma("unroll") for (int i = 0; i < CH; ++i) if (e0 + i < e1)
-              SET_EMIT(i, m.einSrc[e0 + i], m.einSlot[e0 + i], pos - 1, 0, (m.einScore[e0 + i] + m.noGap) + m.sub[m.einBase[e0 + i] * 4 + x], m.einIn[e0 + i], m.einBase[e0 + i])
+              SET_EMIT(i, m.einSrc[e0 + i], m.einSlot[e0 + i], pos - 1, 0, (m.einScore[e0 + i] + m.noGap) + subT[m.einBase[e0 + i] * 4 + x], m.einIn[e0 + i], m.einBase[e0 + i])
             FLUSH(e1 - e0 < CH ? e1 - e0 : CH)
           }
         }
@@ -384,7 +498,7 @@ viterbi_traceback_kernel(DevModel m, const uint8_t* __restrict__ bases, const ui
         int c = 0;
         SET(0, state, ownSlot, pos, 1, m.delEnd, 0)
         c = 1;
-        if (mdl > 0 && pos > 0) { SET(1, state, ownSlot, pos - 1, 2, m.sub[ctx[0] * 4 + seq[pos - 1]], 0) c = 2; }
+        if (mdl > 0 && pos > 0) { SET(1, state, ownSlot, pos - 1, 2, subT[ctx[0] * 4 + seq[pos - 1]], 0) c = 2; }
         if (pos == 0 && m.local) {
           if (c == 1) SET(1, 0, SLOT(0), 0, 0, 0., 0) else SET(2, 0, SLOT(0), 0, 0, 0., 0)
           ++c;
@@ -411,8 +525,8 @@ viterbi_traceback_kernel(DevModel m, const uint8_t* __restrict__ bases, const ui
       } else {
         const int k = mut - 2;
         int c = 0;
-        if (k < mdl - 1) { SET(0, state, ownSlot, pos - 1, 2 + k + 1, m.sub[ctx[k + 1] * 4 + seq[pos - 1]], 0) c = 1; }
-        if (c == 0) SET(0, state, ownSlot, pos, 0, m.tanDup + m.len[k], 0) else SET(1, state, ownSlot, pos, 0, m.tanDup + m.len[k], 0)
+        if (k < mdl - 1) { SET(0, state, ownSlot, pos - 1, 2 + k + 1, subT[ctx[k + 1] * 4 + seq[pos - 1]], 0) c = 1; }
+        if (c == 0) SET(0, state, ownSlot, pos, 0, m.tanDup + lenT[k], 0) else SET(1, state, ownSlot, pos, 0, m.tanDup + lenT[k], 0)
         ++c;
         FLUSH(c)
         if (ev && bestMut == 0) {        // viterbi.cpp:288-293: the duplicated bases, outermost first
@@ -421,7 +535,9 @@ viterbi_traceback_kernel(DevModel m, const uint8_t* __restrict__ bases, const ui
           EVENT(3, pos, ((unsigned)(k + 1) << 26) | (bases & 0x3ffffffu))
         }
       }
+      }   // the step through the CSR arrays
       CHECK_BEST();
+      if (adopt < 0 && state != stateWas) haveRec = false;   // (a fast step has taken the next state's record along)
       if (bestIn) {  // trace.push_front (viterbi.cpp:299-300): fill the slot from its end
         if (n < cap) out[cap - 1 - n] = (char)bestIn;
         ++n;
@@ -436,6 +552,7 @@ viterbi_traceback_kernel(DevModel m, const uint8_t* __restrict__ bases, const ui
 #undef CHECK_BEST
 #undef SET_EMIT
 #undef EVENT
+#undef LOAD_REC
 
   if (evLen) evLen[read] = (uint32_t)(nEv < evCap ? nEv : evCap);
   if (status == 0 && n > cap) status = 2;  // DNAS_READ_OUT_OVERFLOW

@@ -245,6 +245,43 @@ def test_both_traceback_kernels_agree(da, ref_data):
         a.close(); b.close()
 
 
+@pytest.mark.parametrize("machine,options", [("s16h74l4c4.json", "traceback=thread"), ("s16mr2l4c4.json", "traceback=thread"),
+                                             ("mr2l4c4.json", "traceback=thread,tier=B"), ("l4c4.json", "traceback=thread")])
+def test_thread_traceback_with_and_without_node_records(da, ref_data, machine, options, monkeypatch):
+    """The thread-per-read traceback steps from one 64-byte record per state where the state's in-edges fit one (three emitting,
+    one null: device_model.h) and through the CSR arrays where they do not -- s16mr2l4c4 has states with 35 / 73 in-edges, the
+    composites a start state with 98 -- or when DNAS_NO_NODE_RECORDS says so: the same strings either way, and the wave-per-read
+    kernel's; substitutions, deletions and duplications in the reads, global and local, tiers A and B."""
+    m = da.Machine.fromFile(os.path.join(ref_data, machine))
+    rng = random.Random(23)
+    reads = []
+    for i in range(48):
+        dna = list(m.encodeBytes(bytes(rng.randrange(256) for _ in range(1 + i % 9))))
+        for j in range(len(dna)):
+            if rng.random() < 0.04:
+                dna[j] = rng.choice("ACGT")
+        if i % 3 == 0 and len(dna) > 4:
+            del dna[rng.randrange(len(dna))]
+        if i % 4 == 1 and len(dna) > 6:
+            at = rng.randrange(3, len(dna))
+            dna[at:at] = dna[at - 3:at]          # a tandem duplication
+        reads.append("".join(dna))
+    for flags in (dict(global_=True), dict()):
+        params = da.MutatorParams.fromFlags(**flags)
+        wave = da.ViterbiDecoder(m, params, options=options.replace("traceback=thread,", "").replace("traceback=thread", "") or None)
+        want = wave.decode(reads)
+        wave.close()
+        for records in (True, False):
+            if records:
+                monkeypatch.delenv("DNAS_NO_NODE_RECORDS", raising=False)
+            else:
+                monkeypatch.setenv("DNAS_NO_NODE_RECORDS", "1")
+            dec = da.ViterbiDecoder(m, params, options=options)
+            got = dec.decode(reads)
+            dec.close()
+            assert got[0] == want[0] and np.array_equal(got[1].view(np.uint64), want[1].view(np.uint64)) and list(got[2]) == list(want[2]), (machine, flags, records)
+
+
 def test_arena_replanned_when_the_device_has_less_memory_than_at_creation(da, ref_data):
     """The arena cap is taken from the free memory when the model is created.  If the device cannot give that much any more
     (here: a tensor takes all but 20 GB afterwards), the call is planned again against what is free -- more, smaller batches --
