@@ -105,6 +105,32 @@ __device__ __forceinline__ double cell_at(const DevModel& m, const double* __res
   return v;
 }
 
+// Duplication lane k of a state at column ps from the state's node record (device_model.h: mdl, the context's bases 2 bits each,
+// the lattice slot): lattice_cell's chain for at most four S cells (records exist for D <= 4), every one of them loaded before
+// the chain is evaluated -- a loop over them would wait for each load in turn.  SL = lanes stored per column.
+__device__ __forceinline__ double dup_cell_from_record(const double* __restrict__ lat, const uint8_t* __restrict__ seq, size_t SL, size_t stride,
+                                                       int slot, int mdl, unsigned ctxBits, int ps, int k, double tanDup,
+                                                       const double* subT, const double* lenT) {
+  if (SL > 2) return lat[((size_t)ps * SL + (size_t)(2 + k)) * stride + (size_t)slot];
+  if (ps < 1 || k >= mdl) return kNegInf;
+  int I = mdl - 1 - k;
+  if (ps - 1 < I) I = ps - 1;
+  double sv[4];
+  int xb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    sv[i] = i <= I ? lat[((size_t)(ps - i) * SL) * stride + (size_t)slot] : 0.;
+    xb[i] = i < I ? (int)seq[ps - i - 1] : 0;
+  }
+  double v = kNegInf;
+#pragma unroll
+  for (int i = 3; i >= 0; --i) {
+    if (i == I) v = (sv[i] + tanDup) + lenT[k + i];
+    else if (i < I) v = dmax(v + subT[((ctxBits >> (2 * (k + i + 1))) & 3u) * 4 + xb[i]], (sv[i] + tanDup) + lenT[k + i]);
+  }
+  return v;
+}
+
 }  // namespace
 
 // Device-side guard of dnas_viterbi_batch_device: counts base codes outside 0..3.
@@ -385,26 +411,8 @@ viterbi_traceback_kernel(DevModel m, const uint8_t* __restrict__ bases, const ui
           const unsigned ctxR = (hd >> 12) & 0xffu;
           const size_t strideR = (size_t)m.Npad, SL = (size_t)m.storedLanes;
           auto LAT = [&](int ps, int ln, int slot) -> double { return lat[((size_t)ps * SL + (size_t)ln) * strideR + (size_t)slot]; };
-          // own duplication lane k at column ps (lattice_cell's chain, the record's context)
           auto ownT = [&](int ps, int k) -> double {
-            if (SL > 2) return LAT(ps, 2 + k, ownSlotR);
-            if (ps < 1 || k >= mdlR) return kNegInf;
-            int I = mdlR - 1 - k;
-            if (ps - 1 < I) I = ps - 1;
-            // (records exist for D <= 4: at most four S cells, all loaded before the chain is evaluated -- a loop over them
-            //  would wait for every one in turn)
-            double sv[4];
-            int xb[4];
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) {
-              sv[i] = i <= I ? LAT(ps - i, 0, ownSlotR) : 0.;
-              xb[i] = i < I ? (int)seq[ps - i - 1] : 0;
-            }
-            double v = kNegInf;
-            _Pragma("unroll") for (int i = 3; i >= 0; --i) {
-              if (i == I) v = (sv[i] + m.tanDup) + lenT[k + i];
-              else if (i < I) v = dmax(v + subT[((ctxR >> (2 * (k + i + 1))) & 3u) * 4 + xb[i]], (sv[i] + m.tanDup) + lenT[k + i]);
-            }
-            return v;
+            return dup_cell_from_record(lat, seq, SL, strideR, ownSlotR, mdlR, ctxR, ps, k, m.tanDup, subT, lenT);
           };
           const int eSrc[3] = {(int)cur0.z, (int)cur1.y, (int)cur2.x}, eSlot[3] = {(int)cur0.w, (int)cur1.z, (int)cur2.y};
           const unsigned eMisc[3] = {cur1.x, cur1.w, cur2.z};
@@ -582,6 +590,10 @@ viterbi_traceback_wave_kernel(DevModel m, const uint8_t* __restrict__ bases, con
   // Bounded-memory decode (colRange / walks not null): the lattice holds columns colRange[2b] - (D + 1) .. colRange[2b + 1]
   // of read b only.  The walk runs while it stands on a column >= colRange[2b] (a step looks at most D columns back), is
   // then parked in walks[b] and picked up by the launch over the segment before.
+  __shared__ double subT[16], lenT[kMaxLen];   // (as in the thread-per-read kernel: no per-lane index into the kernel-argument block)
+  if (threadIdx.x < 16) subT[threadIdx.x] = m.sub[threadIdx.x];
+  if (threadIdx.x < kMaxLen) lenT[threadIdx.x] = m.len[threadIdx.x];
+  __syncthreads();
   const int b = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
   const int ln = threadIdx.x & 63;
   if (b >= nBatch) return;
@@ -617,6 +629,9 @@ viterbi_traceback_wave_kernel(DevModel m, const uint8_t* __restrict__ bases, con
     curCell = lattice_cell(m, lat, seq, N - 1, L, 0);
   }
 
+  const bool useRec = m.rec != nullptr && ev == nullptr;
+  bool haveW = false;
+  uint4 w0 = {0, 0, 0, 0}, w1 = w0, w2 = w0, w3 = w0;   // the node record of `state`, the same in every lane
   // running best of a step (uniform over the wave)
   double best; bool found; int bState, bPos, bMut; double bCell; uint8_t bIn, bEm;
   // one candidate per lane -> the wave's first strictly greater one, merged into the running best
@@ -654,6 +669,97 @@ viterbi_traceback_wave_kernel(DevModel m, const uint8_t* __restrict__ bases, con
     }
 
     while (pos >= stopBelow && pos >= 0 && state > 0) {
+      // ---- the step from the state's node record (device_model.h), where its in-edges fit one: every lane forms its candidate
+      // from the record (the same in all lanes), loads the candidate's cell AND the candidate state's record, and the winner's
+      // record goes to all lanes with its cell -- one round of memory latency per step instead of three.  The CSR rounds below
+      // serve the other states, the local start column and the event log.
+      const int stateWas = state;
+      bool fastStep = false;
+      if (useRec) {
+        if (!haveW) { const uint4* r_ = (const uint4*)(m.rec + (size_t)state * 16); w0 = r_[0]; w1 = r_[1]; w2 = r_[2]; w3 = r_[3]; haveW = true; }
+        const unsigned hd = w0.x;
+        const int nEr = (int)(hd & 15u), nNr = (int)((hd >> 4) & 15u);
+        if (nEr != 15 && nNr != 15 && !(mut == 0 && pos == 0 && m.local)) {
+          fastStep = true;
+          const int mdlR = (int)((hd >> 8) & 15u), ownSlotR = (int)w0.y;
+          const unsigned ctxR = (hd >> 12) & 0xffu;
+          const size_t strideR = (size_t)m.Npad, SL = (size_t)m.storedLanes;
+          const int x = pos > 0 ? seq[pos - 1] : 0;
+          W_INIT();
+          bool has = false, edge = false;          // edge: the candidate is another state (its record is fetched with its cell)
+          int st = state, slot = ownSlotR, ps = pos, lane_ = 0;
+          double tr = 0.;
+          unsigned in = 0;
+          // in-edge e of the record: emitting 0..2, null 3
+          auto edgeOf = [&](int e, int& src, int& sl, unsigned& misc) {
+            src = e == 0 ? (int)w0.z : e == 1 ? (int)w1.y : e == 2 ? (int)w2.x : (int)w2.w;
+            sl = e == 0 ? (int)w0.w : e == 1 ? (int)w1.z : e == 2 ? (int)w2.y : (int)w3.x;
+            misc = e == 0 ? w1.x : e == 1 ? w1.w : e == 2 ? w2.z : w3.y;
+          };
+          if (mut == 0) {
+            const int nEe = pos > 0 ? nEr : 0;
+            const bool hasT = mdlR > 0 && pos > 0;
+            const int total = nEe + nNr + 1 + (hasT ? 1 : 0);
+            has = ln < total;
+            if (ln < nEe + nNr) {
+              unsigned misc;
+              edgeOf(ln < nEe ? ln : 3, st, slot, misc);
+              edge = true;
+              in = misc & 255u;
+              if (ln < nEe) { ps = pos - 1; tr = (m.recScore[(misc >> 16) & 255u] + m.noGap) + subT[((misc >> 8) & 255u) * 4 + x]; }
+              else tr = m.recScore[(misc >> 16) & 255u];
+            } else if (ln == nEe + nNr) { lane_ = 1; tr = m.delEnd; }
+            else if (has) { ps = pos - 1; lane_ = 2; tr = subT[(ctxR & 3u) * 4 + x]; }
+          } else if (mut == 1) {
+            const int total = 2 * nEr + nNr;
+            has = ln < total;
+            if (has) {
+              unsigned misc;
+              edgeOf(ln < 2 * nEr ? (ln >> 1) : 3, st, slot, misc);
+              edge = true;
+              in = misc & 255u;
+              const double sc = m.recScore[(misc >> 16) & 255u];
+              if (ln < 2 * nEr) { if ((ln & 1) == 0) { lane_ = 1; tr = sc + m.delExtend; } else { lane_ = 0; tr = sc + m.delOpen; } }
+              else { lane_ = 1; tr = sc; }
+            }
+          } else {
+            const int k = mut - 2;
+            const bool shift = k < mdlR - 1;
+            has = ln < (shift ? 2 : 1);
+            const bool first = shift && ln == 0;
+            ps = first ? pos - 1 : pos;
+            lane_ = first ? 2 + k + 1 : 0;
+            tr = first ? subT[((ctxR >> (2 * (k + 1))) & 3u) * 4 + x] : m.tanDup + lenT[k < kMaxLen ? k : 0];
+          }
+          uint4 p0 = {0, 0, 0, 0}, p1 = p0, p2 = p0, p3 = p0;
+          double v = kNegInf, sc = kNegInf;
+          if (has) {
+            if (edge) { const uint4* r_ = (const uint4*)(m.rec + (size_t)st * 16); p0 = r_[0]; p1 = r_[1]; p2 = r_[2]; p3 = r_[3]; }
+            v = lane_ < 2 ? lat[((size_t)ps * SL + (size_t)lane_) * strideR + (size_t)slot]
+                          : dup_cell_from_record(lat, seq, SL, strideR, ownSlotR, mdlR, ctxR, ps, lane_ - 2, m.tanDup, subT, lenT);
+            sc = v + tr;
+          }
+          double bs = sc;
+          int bi = ln;
+          for (int off = 32; off > 0; off >>= 1) {
+            const double os = __shfl_xor(bs, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            if (os > bs || (os == bs && oi < bi)) { bs = os; bi = oi; }
+          }
+          if (bs > best) {
+            best = bs; found = true;
+            bState = __shfl(st, bi, 64); bPos = __shfl(ps, bi, 64); bMut = __shfl(lane_, bi, 64); bCell = __shfl(v, bi, 64);
+            bIn = (uint8_t)__shfl((int)in, bi, 64); bEm = 0;
+            if (__shfl((int)edge, bi, 64)) {       // the next state's record, from the lane that fetched it
+#define W_BCAST(q) { q.x = (unsigned)__shfl((int)q.x, bi, 64); q.y = (unsigned)__shfl((int)q.y, bi, 64); q.z = (unsigned)__shfl((int)q.z, bi, 64); q.w = (unsigned)__shfl((int)q.w, bi, 64); }
+              W_BCAST(p0) W_BCAST(p1) W_BCAST(p2) W_BCAST(p3)
+#undef W_BCAST
+              w0 = p0; w1 = p1; w2 = p2; w3 = p3;
+            }
+          }
+        }
+      }
+      if (!fastStep) {
       // round 1: what the step needs to know about the state, fetched by different lanes
       int meta = 0;
       if (ln == 0) meta = m.einPtr[state]; else if (ln == 1) meta = m.einPtr[state + 1];
@@ -682,7 +788,7 @@ viterbi_traceback_wave_kernel(DevModel m, const uint8_t* __restrict__ bases, con
             if (c < nE) {
               const int e = e0 + c;
               st = m.einSrc[e]; slot = m.einSlot[e]; ps = pos - 1; lane_ = 0;
-              tr = (m.einScore[e] + m.noGap) + m.sub[m.einBase[e] * 4 + x];
+              tr = (m.einScore[e] + m.noGap) + subT[m.einBase[e] * 4 + x];
               in = m.einIn[e]; em = (uint8_t)(1 + m.einBase[e]);
             } else if (c < nE + nN) {
               const int e = n0 + (c - nE);
@@ -690,7 +796,7 @@ viterbi_traceback_wave_kernel(DevModel m, const uint8_t* __restrict__ bases, con
             } else {
               const int q = c - nE - nN;                   // 0: own D, then own T1 (if any), then the local start
               if (q == 0) { st = state; slot = ownSlot; ps = pos; lane_ = 1; tr = m.delEnd; }
-              else if (q == 1 && hasT) { st = state; slot = ownSlot; ps = pos - 1; lane_ = 2; tr = m.sub[ctx0 * 4 + x]; }
+              else if (q == 1 && hasT) { st = state; slot = ownSlot; ps = pos - 1; lane_ = 2; tr = subT[ctx0 * 4 + x]; }
               else { st = 0; slot = WSLOT(0); ps = 0; lane_ = 0; tr = 0.; }
             }
           }
@@ -727,14 +833,16 @@ viterbi_traceback_wave_kernel(DevModel m, const uint8_t* __restrict__ bases, con
         const bool has = ln < total;
         const bool first = shift && ln == 0;
         offer(has, state, ownSlot, first ? pos - 1 : pos, first ? 2 + k + 1 : 0,
-              first ? m.sub[ctxNext * 4 + x] : m.tanDup + m.len[k], 0, 0);
+              first ? subT[ctxNext * 4 + x] : m.tanDup + lenT[k], 0, 0);
         if (ev && bMut == 0) {        // viterbi.cpp:288-293: the duplicated bases, outermost first
           unsigned basesDup = 0;
           for (int q = k; q >= 0; --q) basesDup = (basesDup << 2) | (unsigned)__shfl(meta, 8 + q, 64);
           WEVENT(3, pos, ((unsigned)(k + 1) << 26) | (basesDup & 0x3ffffffu))
         }
       }
+      }   // the step through the CSR arrays
       W_CHECK();
+      if (!fastStep && state != stateWas) haveW = false;   // (a fast step has brought the next state's record along)
       if (bIn) {  // trace.push_front (viterbi.cpp:299-300): fill the slot from its end
         if (ln == 0 && n < cap) out[cap - 1 - n] = (char)bIn;
         ++n;

@@ -247,8 +247,8 @@ def test_both_traceback_kernels_agree(da, ref_data):
 
 @pytest.mark.parametrize("machine,options", [("s16h74l4c4.json", "traceback=thread"), ("s16mr2l4c4.json", "traceback=thread"),
                                              ("mr2l4c4.json", "traceback=thread,tier=B"), ("l4c4.json", "traceback=thread")])
-def test_thread_traceback_with_and_without_node_records(da, ref_data, machine, options, monkeypatch):
-    """The thread-per-read traceback steps from one 64-byte record per state where the state's in-edges fit one (three emitting,
+def test_tracebacks_with_and_without_node_records(da, ref_data, machine, options, monkeypatch):
+    """Both traceback kernels step from one 64-byte record per state where the state's in-edges fit one (three emitting,
     one null: device_model.h) and through the CSR arrays where they do not -- s16mr2l4c4 has states with 35 / 73 in-edges, the
     composites a start state with 98 -- or when DNAS_NO_NODE_RECORDS says so: the same strings either way, and the wave-per-read
     kernel's; substitutions, deletions and duplications in the reads, global and local, tiers A and B."""
@@ -268,9 +268,15 @@ def test_thread_traceback_with_and_without_node_records(da, ref_data, machine, o
         reads.append("".join(dna))
     for flags in (dict(global_=True), dict()):
         params = da.MutatorParams.fromFlags(**flags)
-        wave = da.ViterbiDecoder(m, params, options=options.replace("traceback=thread,", "").replace("traceback=thread", "") or None)
+        wave_options = options.replace("traceback=thread,", "").replace("traceback=thread", "") or None
+        wave = da.ViterbiDecoder(m, params, options=wave_options)
         want = wave.decode(reads)
         wave.close()
+        monkeypatch.setenv("DNAS_NO_NODE_RECORDS", "1")      # the wave-per-read kernel through the CSR arrays
+        wave = da.ViterbiDecoder(m, params, options=wave_options)
+        got = wave.decode(reads)
+        wave.close()
+        assert got[0] == want[0] and np.array_equal(got[1].view(np.uint64), want[1].view(np.uint64)) and list(got[2]) == list(want[2]), (machine, flags)
         for records in (True, False):
             if records:
                 monkeypatch.delenv("DNAS_NO_NODE_RECORDS", raising=False)
