@@ -31,7 +31,7 @@ extern "C" __global__ void fill_neginf_kernel(double*, size_t);
 extern "C" __global__ void check_bases_kernel(const uint8_t*, size_t, unsigned long long*);
 extern "C" __global__ void viterbi_traceback_kernel(DevModel, const uint8_t*, const uint64_t*, const int32_t*,
                                                     const uint64_t*, const double*, char*, const uint64_t*,
-                                                    uint32_t*, uint8_t*, int, unsigned long long*, const uint64_t*, uint32_t*);
+                                                    uint32_t*, uint8_t*, int, unsigned long long*, const uint64_t*, uint32_t*, int);
 
 #define HIP_TRY(expr)                                                                          \
   do {                                                                                         \
@@ -84,7 +84,8 @@ struct dnas_model {
   uint64_t* dSegSlot = nullptr;
   TracebackWalk* dWalks = nullptr;
   bool waveTraceback = true;    // one wave per read for batches of up to 256 reads (option traceback=thread: never)
-  int tbThreads = kTraceThreads;     // reads per block of the thread-per-read traceback (option tb_threads)
+  int tbThreads = kTraceThreads;     // threads per block of the thread-per-read traceback (option tb_threads)
+  int tbLanes = kTraceLanes;         // reads per wave there (option tb_lanes): the other lanes idle
   int maxClusters = 1;          // tier C: clusters that fit the GPU at once
   double* dXbuf = nullptr;      // tier C: exchange buffers, one per cluster
   unsigned* dSync = nullptr;    // tier C: sync blocks (64 u32 per cluster)
@@ -627,6 +628,7 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
   if (const char* s = opt("max_slots")) m->maxSlots = std::max(1, atoi(s));
   if (const char* s = opt("traceback")) m->waveTraceback = !(s[0] == 't' || s[0] == 'T');
   if (const char* s = opt("tb_threads")) m->tbThreads = std::max(64, std::min(256, atoi(s) / 64 * 64));
+  if (const char* s = opt("tb_lanes")) m->tbLanes = std::max(1, std::min(64, atoi(s)));
   if (const char* s = opt("checkpoint")) m->checkpointMode = (s[0] == 'a' && s[1] == 'l') ? 1 : (s[0] == 'n' ? 2 : 0);   // auto | always | never
   if (const char* s = opt("segment")) m->segmentCols = std::max(0, atoi(s));
   if (const char* s = opt("arena_fraction")) {
@@ -1098,7 +1100,8 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
     HIP_TRY(hipEventRecord(m->events[ev + 2], m->stream2));
     // one wave per read finishes a read 4-5x sooner but costs about three times the CU time: for batches small enough
     // that the traceback is what the caller waits for (tier C, short jobs); large batches trace back thread-per-read in
-    // blocks of 128 reads (six CUs for ~18 ms beside the next batch's fill; as two blocks of 512 it held its CUs for 22-37 ms,
+    // blocks of 128 threads, 16 reads per wave (round 4; ~9 ms beside the next batch's fill.  Round 3: 128 reads per block, six CUs
+    // for ~18 ms; as two blocks of 512 it held its CUs for 22-37 ms,
     // and every fifth fill launch paid a fourth round of work-groups on the shader engine it sat on: 51 ms instead of 43.  Also
     // tried: a wave per read launched when the next fill opens its last round -- the work-group that opens it bumped a signal
     // word the traceback stream waited on --: its 180 blocks then crowd the forty idle CUs and every launch took 48 ms) --
@@ -1109,10 +1112,14 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
                          (const double*)m->arena, d_out_sym, (const uint64_t*)m->dOutOff, d_out_len, d_out_status, nB, m->dEvents,
                          (const uint64_t*)m->dEvOff, m->dEvLen, (const int*)nullptr, (TracebackWalk*)nullptr);
     else
-      hipLaunchKernelGGL(viterbi_traceback_kernel, dim3((nB + m->tbThreads - 1) / m->tbThreads), dim3(m->tbThreads), 0,
+    {
+      const int perBlock = (m->tbThreads / 64) * m->tbLanes;     // reads a block walks: tbLanes of every wave's 64 lanes
+      hipLaunchKernelGGL(viterbi_traceback_kernel, dim3((nB + perBlock - 1) / perBlock), dim3(m->tbThreads), 0,
                          m->stream2, d, d_bases, (const uint64_t*)m->dReadOff, (const int32_t*)(m->dBatchRead + s),
                          (const uint64_t*)(m->dSlotOff + s), (const double*)m->arena, d_out_sym,
-                         (const uint64_t*)m->dOutOff, d_out_len, d_out_status, nB, m->dEvents, (const uint64_t*)m->dEvOff, m->dEvLen);
+                         (const uint64_t*)m->dOutOff, d_out_len, d_out_status, nB, m->dEvents, (const uint64_t*)m->dEvOff, m->dEvLen,
+                         m->tbLanes);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(m->events[ev + 3], m->stream2));
     HIP_TRY(hipEventRecord(m->sync[2 * b + 1], m->stream2));

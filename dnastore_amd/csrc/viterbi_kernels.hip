@@ -311,14 +311,19 @@ viterbi_traceback_kernel(DevModel m, const uint8_t* __restrict__ bases, const ui
                          const double* __restrict__ arena, char* __restrict__ outSym,
                          const uint64_t* __restrict__ outOff, uint32_t* __restrict__ outLen,
                          uint8_t* __restrict__ outStatus, int nBatch,
-                         unsigned long long* __restrict__ events, const uint64_t* __restrict__ evOff, uint32_t* __restrict__ evLen) {
+                         unsigned long long* __restrict__ events, const uint64_t* __restrict__ evOff, uint32_t* __restrict__ evLen,
+                         int readsPerWave) {
   // the model's small tables, indexed per lane: from LDS (a per-lane index into the kernel-argument block is a load from
   // wherever the runtime keeps kernel arguments -- host memory, as a rule -- in the middle of every step)
   __shared__ double subT[16], lenT[kMaxLen];
   if (threadIdx.x < 16) subT[threadIdx.x] = m.sub[threadIdx.x];
   if (threadIdx.x < kMaxLen) lenT[threadIdx.x] = m.len[threadIdx.x];
   __syncthreads();
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  // readsPerWave of a wave's 64 lanes walk a read each: the lanes of a wave are at different places of different machines'
+  // states, and a step costs the wave the union of what its lanes do -- fewer reads per wave, fewer paths per step
+  const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = (int)(threadIdx.x & 63);
+  if (lane >= readsPerWave) return;
+  const int b = wave * readsPerWave + lane;
   if (b >= nBatch) return;
   const int read = batchRead[b];
   const uint8_t* seq = bases + readOff[read];

@@ -132,8 +132,9 @@ int dnas_model_create(const dnas_flat_model *fm, int device_id, size_t arena_byt
  * watchdog per lattice column, default 30 s) and cluster_arrive_s (how long the first barrier of a launch waits for work-groups
  * of a cluster that have not been STARTED yet because something else holds their CUs, default 120 s: the members of a cluster
  * wait for each other, so a launch needs all of them resident; when either time runs out the launch is abandoned and the call
- * returns DNAS_E_DEVICE -- until then the waiting work-groups keep their CUs), tb_threads = reads per block of the
- * thread-per-read traceback (multiple of 64, default 128), checkpoint = auto | always | never and
+ * returns DNAS_E_DEVICE -- until then the waiting work-groups keep their CUs), tb_threads = threads per block of the
+ * thread-per-read traceback (multiple of 64, at most 256, default 128) and tb_lanes = reads per wave there (1 .. 64, default 16:
+ * the lanes of a wave stand on different states, and a step costs the wave the union of what they do), checkpoint = auto | always | never and
  * segment = columns (bounded-memory decode of reads whose lattice -- the reference's ViterbiMatrix::cell,
  * viterbi.h:48-50 -- does not fit the arena: segments of the lattice are filled from checkpoints and traced back one
  * after the other; results are bit-identical), traceback = thread, arena_fraction, plan_order = 0 | 1 | 2 and plan_slack = 0 .. 8
