@@ -5,7 +5,7 @@
 
 constexpr int kFillThreads = 1024;  // work-group size of viterbi_fill_kernel (16 waves: one work-group fills a CU)
 constexpr int kTraceLanes = 16;     // reads per wave of the thread-per-read traceback (option tb_lanes): a step costs a wave the union of
-                                    // what its lanes do -- 64 reads per wave: 161 ms per 10 000-read step, 32: 165, 16: 121, 8: 117 (and the fill 1 % slower)
+                                    // what its lanes do -- five pairs of runs, ms per 10 000-read step: 16 reads per wave 118-149, 64 reads 147-221
 constexpr int kTraceThreads = 128;  // independent reads per block of the thread-per-read traceback (see runtime.hip; launch bounds: 256)
 constexpr int kMaxLen = 32;         // pLen entries (dnas_mutator_params.p_len)
 constexpr int kRecEmit = 3, kRecNull = 1;   // in-edges a node record holds inline
