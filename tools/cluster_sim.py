@@ -171,7 +171,7 @@ def main():
         for lr in (int(v) for v in args.load_rows.split(",") if v):
             sw = sim.run(seq, set(), lat, args.cols, load_rows={lr})
             print("lat %2d  fold at row 0, load at row %d: sweeps/col mean %.1f  %s" % (lat, lr, sw[1:].mean(), sw), flush=True)
-        for P in (int(v) for v in args.polls.split(",")):
+        for P in (int(v) for v in args.polls.split(",") if v):
             if P == 0:
                 polls, same = [0], True      # ideal: an offer is in the destination's LDS cell `lat` units later, seen from row 0 on
                 sw = sim.run(seq, set(range(sim.K)), lat, args.cols, fold_same_point=True)
