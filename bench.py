@@ -397,7 +397,7 @@ def viterbi_line(ctx, config, variant, n_reads, steps, warmup, cpu_seconds, time
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s, %d reads/GPU, --error-global, 1%% substitutions" % (wl["name"], n_reads),
                        "reads_per_gpu": n_reads, "total_nt": int(total_nt), "parallelism": "read-sharded x%d" % world,
-                       "inputs": "rank 0 scatter (RCCL)" if scatter else "generated per rank by read index",
+                       "inputs": ("rank 0 scatter (%s)" % ("RCCL" if ctx.backend == "nccl" else ctx.backend)) if scatter else "generated per rank by read index",
                        # which fill kernel and row program served the run, and the tuning record that chose it
                        "program": dec.tier},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
