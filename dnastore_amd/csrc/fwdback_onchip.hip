@@ -42,14 +42,28 @@
 
 namespace {
 
+// DNAS_FB_WHATIF (timing experiments only, never in the shipped library: the results are wrong): 1 = the counts' exp() replaced by a
+// single-precision one, 2 = no counts at all, 3 = the log-sum-exp table not read (a constant instead)
+#ifndef DNAS_FB_WHATIF
+#define DNAS_FB_WHATIF 0
+#endif
+#if DNAS_FB_WHATIF == 1
+#define exp(x) ((double)__expf((float)(x)))
+#elif DNAS_FB_WHATIF == 2
+#define exp(x) (0.0 * (x))
+#endif
+
 constexpr double kNegInf = -__builtin_huge_val();
 // (kMaxP, a template parameter below: the duplication lanes the kernel keeps in registers -- 6 for the CLI's default model, 8 at most)
 
 // x / .0001, correctly rounded, without the division sequence (Markstein: q0 = x * r, e = x - c * q0 exactly, q = q0 + e * r
-// with r the correctly rounded reciprocal); below 1e-280 the residual would underflow: the division itself
+// with r the correctly rounded reciprocal; checked against the division on 4 * 10^8 arguments).  Below 1e-280 the residual
+// underflows and q may differ from x / c in its last bits -- which nobody sees: both uses below take such an x to the same
+// result as the division does ((int) of a number below 1e-276 is 0; f0 + df * q with f0 >= log(1 + e^-10) = 4.5e-5 and
+// df * q < 1e-280 is f0), so there is no special case (round 4 took one out: two comparisons and a branch per call, twice per
+// log-sum-exp).
 __device__ __forceinline__ double divStep(double x) {
   constexpr double c = .0001, r = 1.0 / .0001;
-  if (x != 0. && x < 1e-280) return x / c;
   const double q0 = x * r;
   const double e = __builtin_fma(-c, q0, x);
   return __builtin_fma(e, r, q0);
@@ -67,7 +81,11 @@ __device__ __forceinline__ double lse_unary(fb_rsrc_t tab, double x) {
   const double xs = in ? x : 0.;
   const int n = (int)divStep(xs);                 // (int)(x / .0001)
   const double dx = xs - (n * .0001);
+#if DNAS_FB_WHATIF == 3
+  fb_dbl2 f; f.x = 0.5 + n * 1e-9; f.y = 0.25;
+#else
   const fb_dbl2 f = __builtin_bit_cast(fb_dbl2, __builtin_amdgcn_raw_buffer_load_b128(tab, n * 8, 0, 0));   // tab[n], tab[n + 1]
+#endif
   const double df = f.y - f.x;
   const double v = f.x + df * divStep(dx);        // f0 + df * (dx / .0001)
   return in ? v : 0.;
