@@ -124,7 +124,8 @@ __device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_
   double* const SUBC = base;                                         // [16] substitution counts
   double* const SUBS_ = SUBC + 16;                                   // [16] the substitution scores
   double* const LENS_ = SUBS_ + 16;                                  // [8]
-  short* const LO = reinterpret_cast<short*>(LENS_ + 8);             // [maxInLen + 2]
+  double* const ACC = LENS_ + 8;                                     // [16] the pair's other counts: c0..c4, then the length counts
+  short* const LO = reinterpret_cast<short*>(ACC + 16);              // [maxInLen + 2]
   short* const HI = LO + (maxInLen + 2);
   // scratch of this slot: every Forward cell of the pair
   const size_t compStride = (size_t)maxSteps * 64;                   // doubles between two components of a cell
@@ -154,7 +155,7 @@ __device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_
   // ---- the envelope of every row (alignpath.h:48-53): op in [lo, hi] <=> |cm(ip) - cm(op)| <= maxDistance; cm is
   // non-decreasing along both sequences, so lo and hi are two binary searches per row
   WAVE_SYNC();
-  for (int i = l; i < 16; i += W) SUBC[i] = 0;
+  for (int i = l; i < 16; i += W) { SUBC[i] = 0; ACC[i] = 0; }
   for (int ip = l; ip <= I; ip += W) {
     const int lowKey = ci[ip] - Dm, highKey = ci[ip] + Dm;
     int x = 0, y = O + 1;
@@ -242,9 +243,7 @@ __device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_
 
   // ---------------- pass 2: Backward (fwdback.cpp:80-116), anti-diagonals downwards, with the counts.  The row below (ip+1)
   // belongs to the lane above: its cells (ip+1, op+1) and (ip+1, op) were finished two steps and one step ago
-  double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, cl[kMaxP];
-#pragma unroll
-  for (int k = 0; k < kMaxP; ++k) cl[k] = 0;
+  // (the counts are added up in LDS, like the substitution counts: as registers they were 22 more of a cell that spills as it is)
   {
     int ip = (live && l <= I) ? l + ((I - l) / W) * W : -1;        // this lane's last row
     const int aFirst = live ? I + HI[I] : -1, aEnd = live ? LO[0] : 0;
@@ -302,7 +301,7 @@ __device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_
           // ---- posterior counts at (ip, op) (fwdback.h:92-112)
           if (ip > 0 && op > 0) {
             const double cS = exp(fUpDiagS + a.noGap + SUBS(ip, op) + s - ll);                     // pS2S
-            c2 += cS;
+            atomicAdd(&ACC[2], cS);
             double subAdd = cS;
 #pragma unroll
             for (int k = 0; k < kMaxP - 1; ++k)
@@ -312,18 +311,20 @@ __device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_
             atomicAdd(&SUBC[in[ip - 1] * 4 + out[op - 1]], subAdd);
           }
           if (ip > 0) {
-            c0 += exp(fUpS + a.delOpen + d - ll);                                                  // pS2D
-            c3 += exp(fUpD + a.delExtend + d - ll);                                                // pD2D
+            atomicAdd(&ACC[0], exp(fUpS + a.delOpen + d - ll));                                    // pS2D
+            atomicAdd(&ACC[3], exp(fUpD + a.delExtend + d - ll));                                  // pD2D
           }
-          c4 += exp(fOwnD + a.delEnd + s - ll);                                                    // pD2S
+          atomicAdd(&ACC[4], exp(fOwnD + a.delEnd + s - ll));                                      // pD2S
           const double fs = fOwnS;
+          double cTsum = 0;
 #pragma unroll
           for (int k = 0; k < kMaxP; ++k)
             if (k < mdl) {
               const double cT = exp(fs + a.tanDup + LENS_[k] + bt[k] - ll);                        // pS2T
-              c1 += cT;
-              cl[k] += cT;
+              cTsum += cT;
+              atomicAdd(&ACC[5 + k], cT);
             }
+          atomicAdd(&ACC[1], cTsum);
           if (op == lo) ip -= W;                                   // row done: on to this lane's next row up
         } else if (op < lo) {
           ip -= W;                                                 // (an empty row)
@@ -333,20 +334,13 @@ __device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_
   }
   WAVE_SYNC();
 
-  // ---- the pair's counts: lanes summed in a fixed tree
-  auto sumW = [&](double v) {
-    for (int offs = W / 2; offs > 0; offs >>= 1) v += __shfl_xor(v, offs, W);
-    return v;
-  };
-  c0 = sumW(c0); c1 = sumW(c1); c2 = sumW(c2); c3 = sumW(c3); c4 = sumW(c4);
-#pragma unroll
-  for (int k = 0; k < kMaxP; ++k) cl[k] = sumW(cl[k]);
+  // ---- the pair's counts
   if (live) {
     double* pc = pairCounts + (size_t)pair * (21 + P);
     if (l == 0) {
-      pc[0] = c0; pc[1] = c1; pc[2] = c2; pc[3] = c3; pc[4] = c4;
+      pc[0] = ACC[0]; pc[1] = ACC[1]; pc[2] = ACC[2]; pc[3] = ACC[3]; pc[4] = ACC[4];
 #pragma unroll
-      for (int k = 0; k < kMaxP; ++k) if (k < P) pc[21 + k] = cl[k];
+      for (int k = 0; k < kMaxP; ++k) if (k < P) pc[21 + k] = ACC[5 + k];
     }
     for (int i = l; i < 16; i += W) pc[5 + i] = SUBC[i];
   }
