@@ -43,7 +43,8 @@
 namespace {
 
 // DNAS_FB_WHATIF (timing experiments only, never in the shipped library: the results are wrong): 1 = the counts' exp() replaced by a
-// single-precision one, 2 = no counts at all, 3 = the log-sum-exp table not read (a constant instead)
+// single-precision one, 2 = no counts at all, 3 = the log-sum-exp table not read (a constant instead), 4 = the bases not loaded
+// (the substitution scores indexed by the cell's coordinates), 5 = ... and the score table in LDS not read either
 #ifndef DNAS_FB_WHATIF
 #define DNAS_FB_WHATIF 0
 #endif
@@ -136,8 +137,16 @@ __device__ __forceinline__ void fwdback_onchip_body(const FbArgs& a, const int8_
   unsigned long long nLse = 0;
   const fb_rsrc_t lseRsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(lseTab), 0, 100001 * 8, 0x00020000);
 #define LSE(x, y) (++nLse, lse(lseRsrc, (x), (y)))
+#if DNAS_FB_WHATIF == 4      /* the bases not loaded */
+#define SUBS(i, o) SUBS_[((i) & 3) * 4 + ((o) & 3)]
+#define DUPS(i, o, k) SUBS_[(((i) - (k)) & 3) * 4 + ((o) & 3)]
+#elif DNAS_FB_WHATIF == 5    /* ... and the score table not read either */
+#define SUBS(i, o) (-0.01 * (((i) + (o)) & 3))
+#define DUPS(i, o, k) (-0.01 * (((i) + (o) + (k)) & 3))
+#else
 #define SUBS(i, o) SUBS_[in[(i) - 1] * 4 + out[(o) - 1]]                 /* cellSubScore, fwdback.h:65-67 */
 #define DUPS(i, o, k) SUBS_[in[(i) - 1 - (k)] * 4 + out[(o) - 1]]        /* cellTanDupScore, fwdback.h:69-71 */
+#endif
 #define WAVE_SYNC() __builtin_amdgcn_wave_barrier()                      /* LDS traffic of one wave is in order: a compiler fence */
 #define FROM_LANE(v, src) __shfl((v), (src), W)
 
