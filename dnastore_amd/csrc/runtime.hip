@@ -28,6 +28,8 @@ extern "C" __global__ void viterbi_traceback_wave_kernel(DevModel, const uint8_t
                                                          uint32_t*, uint8_t*, int, unsigned long long*, const uint64_t*, uint32_t*,
                                                          const int*, TracebackWalk*);
 extern "C" __global__ void fill_neginf_kernel(double*, size_t);
+extern "C" __global__ void sync_latency_kernel(unsigned*, int, int, int, unsigned long long*, unsigned*);
+extern "C" __global__ void xcc_probe_kernel(unsigned*);
 extern "C" __global__ void check_bases_kernel(const uint8_t*, size_t, unsigned long long*);
 extern "C" __global__ void viterbi_traceback_kernel(DevModel, const uint8_t*, const uint64_t*, const int32_t*,
                                                     const uint64_t*, const double*, char*, const uint64_t*,
@@ -89,6 +91,12 @@ struct dnas_model {
   int maxClusters = 1;          // tier C: clusters that fit the GPU at once
   double* dXbuf = nullptr;      // tier C: exchange buffers, one per cluster
   unsigned* dSync = nullptr;    // tier C: sync blocks (64 u32 per cluster)
+  unsigned* dSyncBase = nullptr;   // ... and the allocation they sit in: the blocks are placed inside it by measured latency
+  std::string syncPlaceNote;
+  std::vector<double> syncLat;     // [8 XCCs][syncCand] measured round trips (ticks), by the XCC id the measuring block ran on; empty: not measured
+  int syncCand = 0;
+  size_t syncOffNow = 0;           // where the blocks sit in their window right now
+  unsigned* xccProbe = nullptr;    // pinned host word the probe kernel writes
   unsigned* dFoldTab = nullptr; // tier C: inbox slot -> LDS cells, per member
   size_t xStride = 0;           // doubles per cluster in dXbuf
   unsigned long long timeoutTicks = 0, arriveTicks = 0;
@@ -141,6 +149,31 @@ struct dnas_model {
   uint32_t* dEvLen = nullptr;
   std::vector<uint64_t> evOff;
 };
+
+constexpr size_t kSyncWindow = 64 * 1024, kSyncStep = 1024;   // the sync blocks of a tier-C model sit somewhere in a window this much longer than they are
+
+// Where in their window the sync blocks serve a launch best, given the measured round trips (m->syncLat) and the XCC the launch's
+// block 0 -- cluster 0 -- is expected on: cluster c of a launch runs on the XCC c after it (whole clusters per XCD), the clusters of
+// a spread plan on all of them.  The first cluster counts four times: a launch of ONE cluster is what latency is asked of.
+static size_t place_sync_words(const dnas_model* m, unsigned firstXcc) {
+  if (m->syncLat.empty()) return 0;
+  const int first = std::min(8, m->maxClusters), nC = m->syncCand;
+  double best = -1;
+  size_t at = 0;
+  for (size_t off = 0; off <= kSyncWindow; off += kSyncStep) {
+    double cost = 0;
+    for (int c = 0; c < first; ++c) {
+      const size_t k = (off + (size_t)c * 256) / kSyncStep;
+      if ((int)k >= nC) { cost = -1; break; }
+      double t = 0;
+      if (m->clusterSpread) { for (int x = 0; x < 8; ++x) t += m->syncLat[(size_t)x * nC + k] / 8; }
+      else t = m->syncLat[(size_t)((firstXcc + (unsigned)c) & 7u) * nC + k];
+      cost += (c == 0 ? 4.0 : 1.0) * t;
+    }
+    if (cost >= 0 && (best < 0 || cost < best)) { best = cost; at = off; }
+  }
+  return at;
+}
 
 namespace {
 
@@ -198,6 +231,7 @@ int collect_stats(dnas_model* m) {
       if (w[1]) return dnas::fail(DNAS_E_DEVICE, "tier C: a cluster did not agree on a lattice column within the watchdog time, or its work-groups were "
                                                  "not all started within the arrival time (launch aborted; options cluster_timeout_s, cluster_arrive_s)");
       if (w[40]) { ++clusters; if (w[40] & (w[40] - 1)) ++xccMixed; }
+      if (c == 0 && getenv("DNAS_SYNC_DEBUG")) fprintf(stderr, "sync debug: cluster 0 ran on XCC mask 0x%x\n", w[40]);
     }
     m->clustersSeen = clusters; m->clustersSplit = xccMixed;
   }
@@ -566,11 +600,56 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
             if (m->clusterSpread) m->maxClusters = std::max(1, cus / p.G);
             if (const char* s = opt("max_clusters")) m->maxClusters = std::max(1, atoi(s));
             m->xStride = (size_t)p.exchangeStride();
+            // the sync blocks sit in a window of 64 KB more than they need: their place in it is chosen below
+            size_t syncOff = kSyncWindow;
             if (hipMalloc((void**)&m->dXbuf, m->xStride * (size_t)m->maxClusters * sizeof(double)) != hipSuccess ||
-                hipMalloc((void**)&m->dSync, (size_t)m->maxClusters * 64 * sizeof(unsigned)) != hipSuccess ||
+                hipMalloc((void**)&m->dSyncBase, (size_t)m->maxClusters * 64 * sizeof(unsigned) + syncOff) != hipSuccess ||
                 hipMalloc((void**)&m->dFoldTab, std::max<size_t>(p.foldTab.size(), 1) * 4) != hipSuccess ||
                 hipMemcpy(m->dFoldTab, p.foldTab.data(), p.foldTab.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
               throw std::runtime_error("tier C exchange buffer allocation failed");
+            // WHERE in the window: the members of a cluster agree on every column through device-scope atomics on their sync block,
+            // performed at the memory side -- the round trip from an XCD depends on the memory channel the address belongs to (one
+            // read alone on 16 work-groups: 41.6 ms or 54 ms with the block 4 KB apart; a full launch of 64 clusters does not care,
+            // its blocks spread over the channels).  sync_latency_kernel times the round trip from every XCD to a candidate
+            // every KB; the offset is taken that serves the first clusters of a launch best (cluster c runs on the XCD of block
+            // c % 8; the clusters of a spread plan on all of them), the first one -- a single read's -- above all.
+            // DNAS_SYNC_OFFSET=<bytes> forces a place (experiments), sync_place=0 takes the start of the window.
+            syncOff = 0;
+            if (const char* e = getenv("DNAS_SYNC_OFFSET")) syncOff = std::min((size_t)atol(e) & ~(size_t)255, kSyncWindow);
+            else if (!(opt("sync_place") && atoi(opt("sync_place")) == 0)) {
+              const int nCand = (int)(kSyncWindow / kSyncStep) + 16, reps = 12;    // (the blocks of the first clusters reach past the offset)
+              unsigned long long* dLat = nullptr;
+              unsigned* dXcc = nullptr;
+              std::vector<unsigned long long> lat((size_t)8 * nCand, 0ull);
+              if (hipMalloc((void**)&dLat, lat.size() * sizeof(unsigned long long)) == hipSuccess && hipMalloc((void**)&dXcc, 8 * sizeof(unsigned)) == hipSuccess &&
+                  hipMemsetAsync(m->dSyncBase, 0, (size_t)m->maxClusters * 64 * sizeof(unsigned) + kSyncWindow, m->stream) == hipSuccess) {
+                const int candAvail = (int)std::min<size_t>((size_t)nCand, ((size_t)m->maxClusters * 64 * sizeof(unsigned) + kSyncWindow) / kSyncStep);
+                hipLaunchKernelGGL(sync_latency_kernel, dim3(8), dim3(64), 0, m->stream, m->dSyncBase, candAvail, (int)(kSyncStep / sizeof(unsigned)), reps, dLat, dXcc);
+                if (hipGetLastError() == hipSuccess &&
+                    hipMemcpyAsync(lat.data(), dLat, (size_t)8 * candAvail * sizeof(unsigned long long), hipMemcpyDeviceToHost, m->stream) == hipSuccess &&
+                    hipStreamSynchronize(m->stream) == hipSuccess) {
+                  std::vector<unsigned> xcc(8, 0);
+                  (void)hipMemcpy(xcc.data(), dXcc, 8 * sizeof(unsigned), hipMemcpyDeviceToHost);
+                  m->syncCand = candAvail;
+                  m->syncLat.assign((size_t)8 * candAvail, 0.);
+                  for (int b = 0; b < 8; ++b)
+                    for (int k = 0; k < candAvail; ++k) m->syncLat[(size_t)(xcc[(size_t)b] & 7u) * candAvail + k] = (double)lat[(size_t)b * candAvail + k];
+                  syncOff = place_sync_words(m, 0);
+                  m->syncPlaceNote = "sync words at +" + std::to_string(syncOff) + " B";
+                  if (getenv("DNAS_SYNC_DEBUG")) {
+                    fprintf(stderr, "sync debug: calibration blocks ran on XCCs");
+                    for (int b = 0; b < 8; ++b) fprintf(stderr, " %u", xcc[(size_t)b]);
+                    fprintf(stderr, "; offset %zu; block 0 ticks per candidate:", syncOff);
+                    for (int k = 0; k < candAvail; k += 4) fprintf(stderr, " %llu", lat[(size_t)k]);
+                    fprintf(stderr, "\n");
+                  }
+                }
+              }
+              if (dLat) (void)hipFree(dLat);
+              if (dXcc) (void)hipFree(dXcc);
+            }
+            m->syncOffNow = syncOff;
+            m->dSync = m->dSyncBase + syncOff / sizeof(unsigned);
             // watchdog per lattice column.  A column takes tens of microseconds, but the clock keeps running while the device's
             // scheduler lets another queue's kernel run: the limit only has to turn a protocol failure into an error instead
             // of a hung GPU.  (Two cluster launches at once on one card take turns launch by launch; the stalls of 2-6 s once
@@ -583,7 +662,8 @@ extern "C" int dnas_model_create_ex(const dnas_flat_model* fm, int device_id, si
             m->arriveTicks = (unsigned long long)(arrive * 1e8);
             m->tier = 2;
             m->tierNote = "tier C: " + std::to_string(p.G) + " work-groups per read, " + std::to_string(m->maxClusters) +
-                          (m->clusterSpread ? " clusters dealt over the XCDs, exchange edges " : " clusters, exchange edges ") + std::to_string(p.crossEdges) + ", " + p.key + "; " + recordNote;
+                          (m->clusterSpread ? " clusters dealt over the XCDs, exchange edges " : " clusters, exchange edges ") + std::to_string(p.crossEdges) + ", " + p.key + "; " + recordNote +
+                          (m->syncPlaceNote.empty() ? "" : "; " + m->syncPlaceNote);
           }
         } catch (const std::exception& e) {
           m->tier = 0;
@@ -658,9 +738,10 @@ extern "C" void dnas_model_destroy(dnas_model* m) {
   if (m->dMetaTab) (void)hipFree(m->dMetaTab);
   if (m->dSlotOf) (void)hipFree(m->dSlotOf);
   if (m->dXbuf) (void)hipFree(m->dXbuf);
-  if (m->dSync) (void)hipFree(m->dSync);
+  if (m->dSyncBase) (void)hipFree(m->dSyncBase);
   if (m->dFoldTab) (void)hipFree(m->dFoldTab);
   if (m->syncCheck) (void)hipHostFree(m->syncCheck);
+  if (m->xccProbe) (void)hipHostFree(m->xccProbe);
   if (m->dEvents) (void)hipFree(m->dEvents);
   if (m->dEvOff) (void)hipFree(m->dEvOff);
   if (m->dEvLen) (void)hipFree(m->dEvLen);
@@ -859,7 +940,28 @@ struct FillLauncher {
       const size_t nX = m->xStride * (size_t)nClusters;
       hipLaunchKernelGGL(fill_neginf_kernel, dim3((unsigned)((nX + 255) / 256)), dim3(256), 0, m->stream, m->dXbuf, nX);
       HIP_TRY(hipGetLastError());
-      HIP_TRY(hipMemsetAsync(m->dSync, 0, (size_t)nClusters * 64 * sizeof(unsigned), m->stream));
+      if (!m->syncLat.empty() && !m->clusterSpread && nClusters <= 8) {
+        // A launch of a few clusters -- one read alone -- is a latency matter, and which XCD its first block goes to is not fixed:
+        // the dispatcher deals the work-groups of successive kernels round the XCDs in one sequence.  A one-block probe says where
+        // that sequence stands right now (the fill is the next kernel: its block 0 goes where the probe's one block went -- observed
+        // over and over, `DNAS_SYNC_DEBUG=1` prints both), and the
+        // sync blocks move to the place in their window that this XCD reaches soonest.  Speed only: a wrong guess costs what a
+        // badly placed block costs, 42 against 54 ms for a ~980-nt read of the 46 670-state machine on 16 work-groups.
+        if (!m->xccProbe) HIP_TRY(hipHostMalloc((void**)&m->xccProbe, sizeof(unsigned), hipHostMallocDefault));
+        HIP_TRY(hipMemsetAsync(m->dSyncBase, 0, (size_t)m->maxClusters * 64 * sizeof(unsigned) + kSyncWindow, m->stream));
+        *m->xccProbe = 0xffu;
+        hipLaunchKernelGGL(xcc_probe_kernel, dim3(1), dim3(64), 0, m->stream, m->xccProbe);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        if (*m->xccProbe < 8u) {
+          m->syncOffNow = place_sync_words(m, *m->xccProbe & 7u);
+          m->dSync = m->dSyncBase + m->syncOffNow / sizeof(unsigned);
+          la.syncWords = m->dSync;
+          if (getenv("DNAS_SYNC_DEBUG")) fprintf(stderr, "sync debug: probe on XCC %u, sync words at +%zu\n", *m->xccProbe, m->syncOffNow);
+        }
+      } else {
+        HIP_TRY(hipMemsetAsync(m->dSync, 0, (size_t)nClusters * 64 * sizeof(unsigned), m->stream));
+      }
     }
     size_t laSize = sizeof la;
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &la, HIP_LAUNCH_PARAM_BUFFER_SIZE, &laSize, HIP_LAUNCH_PARAM_END};
@@ -1070,6 +1172,7 @@ extern "C" int dnas_viterbi_batch_device(dnas_model* m, int64_t n_reads, const u
     const size_t wantWords = (nBatches + cp.groupLaunches) * (size_t)m->maxClusters * 64;
     if (wantWords > m->syncCheckCap) {
       if (m->syncCheck) (void)hipHostFree(m->syncCheck);
+  if (m->xccProbe) (void)hipHostFree(m->xccProbe);
       m->syncCheck = nullptr; m->syncCheckCap = 0; m->syncCheckWords = 0;
       HIP_TRY(hipHostMalloc((void**)&m->syncCheck, wantWords * sizeof(unsigned), hipHostMallocDefault));   // pinned: the copies after each fill stay asynchronous
       m->syncCheckCap = wantWords;

@@ -141,6 +141,39 @@ extern "C" __global__ void check_bases_kernel(const uint8_t* __restrict__ bases,
 }
 
 // -inf into every cell of the tier-C exchange buffers before a launch.
+// Where should a cluster's sync words sit?  The members of a cluster agree on every lattice column through device-scope
+// atomics and loads on a few words (viterbi_tiera.hip): operations performed at the memory side, whose round trip from an XCD
+// depends on which memory channel the address belongs to (measured on MI355X: one ~980-nt read of the 46 670-state machine on
+// 16 work-groups fills in 41.6 ms with its sync block at one address and in 54 ms 4 KB further on, same box, same process).
+// Block b of this kernel (b = 0 .. 7: the XCD that block b, b + 8, ... of a launch are dispatched to) times `reps` dependent
+// atomic round trips to each of nCand candidate addresses, pool + k * strideWords, and files the ticks under out[b * nCand + k].
+extern "C" __global__ void sync_latency_kernel(unsigned* __restrict__ pool, int nCand, int strideWords, int reps,
+                                               unsigned long long* __restrict__ out, unsigned* __restrict__ xccOut) {
+  if (threadIdx.x != 0) return;
+  const int b = (int)blockIdx.x;
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  xccOut[b] = xcc & 15u;
+  for (int i = 0; i < nCand; ++i) {
+    const int k = (i + b * 5) % nCand;      // (the blocks walk the candidates out of step)
+    unsigned* const p = pool + (size_t)k * (size_t)strideWords;
+    unsigned dep = __hip_atomic_fetch_add(p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // warm: page tables, the line
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int r = 0; r < reps; ++r) dep = __hip_atomic_fetch_add(p + (dep & 0u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    out[(size_t)b * nCand + k] = t1 - t0 + (dep & 0u);
+  }
+}
+
+// Which XCD is next in the dispatcher's round?  (One block: the first block of the kernel launched right behind this one goes to
+// the same XCD -- observed; a matter of speed only.)
+extern "C" __global__ void xcc_probe_kernel(unsigned* __restrict__ out) {
+  if (threadIdx.x != 0) return;
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  *out = xcc & 15u;
+}
+
 extern "C" __global__ void fill_neginf_kernel(double* __restrict__ p, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = kNegInf;

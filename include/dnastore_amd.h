@@ -132,7 +132,10 @@ int dnas_model_create(const dnas_flat_model *fm, int device_id, size_t arena_byt
  * watchdog per lattice column, default 30 s) and cluster_arrive_s (how long the first barrier of a launch waits for work-groups
  * of a cluster that have not been STARTED yet because something else holds their CUs, default 120 s: the members of a cluster
  * wait for each other, so a launch needs all of them resident; when either time runs out the launch is abandoned and the call
- * returns DNAS_E_DEVICE -- until then the waiting work-groups keep their CUs), tb_threads = threads per block of the
+ * returns DNAS_E_DEVICE -- until then the waiting work-groups keep their CUs), sync_place = 0 | 1 (tier C, default 1: the words
+ * the members of a cluster agree through are put where the device-scope round trip from the cluster's XCD measures shortest --
+ * the memory channel matters: one read alone fills in 42 ms or 54 ms --, a few milliseconds when the model is made; 0: wherever
+ * the allocation starts), tb_threads = threads per block of the
  * thread-per-read traceback (multiple of 64, at most 256, default 128) and tb_lanes = reads per wave there (1 .. 64, default 16:
  * the lanes of a wave stand on different states, and a step costs the wave the union of what they do), checkpoint = auto | always | never and
  * segment = columns (bounded-memory decode of reads whose lattice -- the reference's ViterbiMatrix::cell,

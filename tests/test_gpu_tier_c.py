@@ -265,3 +265,26 @@ def test_tier_c_clusters_split_over_xcds(da, oracle_mod, ref_data, mach, fa, fla
             lat = np.ascontiguousarray(dec.lattice(i, len(r)).transpose(0, 2, 1))
             assert np.array_equal(lat.view(np.uint64), res[2].view(np.uint64))
     dec.close()
+
+
+def test_sync_words_are_placed_by_measured_latency(da, oracle_mod, ref_data, monkeypatch):
+    """Where a cluster's sync words sit is a matter of speed only (option sync_place, DNAS_SYNC_OFFSET): the place the library
+    measures, the start of the window and two forced offsets give the same strings and log-likelihood bits, which are the
+    oracle's; the chosen place is named in the tier note."""
+    O = oracle_mod
+    path = os.path.join(ref_data, "s16h74l4c4.json")
+    flags = dict(global_=True)
+    m = da.Machine.fromFile(path)
+    orc = O.ViterbiOracle(O.Machine.from_file(path), O.MutatorParams.from_cli(**flags))
+    reads = [m.encodeBytes(bytes([3 * i % 256, 255 - i, 11 * i % 256, i])) for i in range(9)]
+    want = [orc.decode(r)[:2] for r in reads]
+    for opts, env in (("tier=C,cluster=3", None), ("tier=C,cluster=3,sync_place=0", None), ("tier=C,cluster=3", "2048"), ("tier=C,cluster=3", "65536")):
+        if env is None:
+            monkeypatch.delenv("DNAS_SYNC_OFFSET", raising=False)
+        else:
+            monkeypatch.setenv("DNAS_SYNC_OFFSET", env)
+        dec = da.ViterbiDecoder(m, da.MutatorParams.fromFlags(**flags), options=opts)
+        out, ll, st = dec.decode(reads)
+        assert ("sync words at" in dec.tier) == (env is None and "sync_place=0" not in opts), dec.tier
+        assert [(o, float(x)) for o, x in zip(out, ll)] == [(w[0], float(w[1])) for w in want]
+        dec.close()
