@@ -14,7 +14,7 @@ reads = bench.make_reads(m, 0, 1, payload_bytes=wl["payload_bytes"])
 offs = sys.argv[1:] or ["placed", "start", "0", "1024", "4096", "8192", "16384", "32768", "65536", "placed", "placed"]
 for off in offs:
     os.environ.pop("DNAS_SYNC_OFFSET", None)
-    opts = "threads=512,cluster=16"
+    opts = os.environ.get("PROBE_PLAN", "threads=512,cluster=16")     # PROBE_PLAN="threads=512,cluster=4": the throughput plan's clusters
     if off == "start":
         opts += ",sync_place=0"
     elif off != "placed":
