@@ -231,7 +231,7 @@ int collect_stats(dnas_model* m) {
       if (w[1]) return dnas::fail(DNAS_E_DEVICE, "tier C: a cluster did not agree on a lattice column within the watchdog time, or its work-groups were "
                                                  "not all started within the arrival time (launch aborted; options cluster_timeout_s, cluster_arrive_s)");
       if (w[40]) { ++clusters; if (w[40] & (w[40] - 1)) ++xccMixed; }
-      if (c == 0 && getenv("DNAS_SYNC_DEBUG")) fprintf(stderr, "sync debug: cluster 0 ran on XCC mask 0x%x\n", w[40]);
+      if (c == 0 && getenv("DNAS_SYNC_DEBUG")) fprintf(stderr, "sync debug: cluster 0 ran on XCC mask 0x%x, its epoch word counted %u bumps\n", w[40], w[0]);
     }
     m->clustersSeen = clusters; m->clustersSplit = xccMixed;
   }

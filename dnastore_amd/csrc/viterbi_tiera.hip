@@ -119,7 +119,7 @@ struct TierAArgs {
   double score[4];  // score table, score[0] == 0
 };
 
-// LDS map (bytes):  SC[SROWS*T] | pad | DC[NS] | score[4] | sub[16] | len[8] | red[T/64] | epoch, idle[T/64], done, ge, abort (u32)
+// LDS map (bytes):  SC[SROWS*T] | pad | DC[NS] | score[4] | sub[16] | len[8] | red[T/64] | epoch, idle[T/64], done, ge, abort, pend (u32)
 constexpr int kDCBase = DNAS_SROWS * DNAS_T * 8 + 64;
 constexpr int kTabBase = kDCBase + DNAS_NS * 8;
 
@@ -263,6 +263,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
   unsigned* const doneL = idleL + DNAS_T / 64;
   unsigned* const geL = doneL + 1;
   unsigned* const abortL = doneL + 2;
+  unsigned* const pendL = doneL + 3;      // clusters: waves whose exchange offers have completed since wave 0 last told the cluster (below)
 
   // ---- who am I: tier A one work-group per read; tier C member `member` of cluster `cluster`, which
   // walks the reads cluster, cluster + nClusters, ...  Blocks b and b + 8 land on the same XCD (observed
@@ -356,7 +357,7 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
   if (tid < 4) lds[kTabBase / 8 + tid] = a.score[tid];
   if (tid < 16) lds[kTabBase / 8 + 4 + tid] = a.sub[tid];
   if (tid < 8) lds[kTabBase / 8 + 20 + tid] = a.len[tid];
-  if (tid < 4 + DNAS_T / 64) epochL[tid] = 0;
+  if (tid < 5 + DNAS_T / 64) epochL[tid] = 0;
   __syncthreads();
 
   // The S and D lanes of column p leave for HBM from the registers, 16 bytes per lane (rows 2m and
@@ -558,9 +559,12 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
     // read when its turn comes, so a value crosses every forward edge (source row < destination
     // row) within one sweep -- the plan lays the machine's chains out along ascending rows.
     //
-    // Cluster: the same one level up.  GE is bumped by a wave after its exchange offers have completed
-    // (in its next sweep, behind an s_waitcnt vmcnt(0); a sweep that offered something is never the idle
-    // one; and s_waitcnt vmcnt(0) again before the wave may call itself idle, so that its own bump has landed).  Wave 0 reads GE in every sweep and turns a change into a bump of the work-group's
+    // Cluster: the same one level up.  GE is bumped once the exchange offers of a wave have completed: the wave says so in LDS
+    // (`pend`, in its next sweep, behind an s_waitcnt vmcnt(0); a sweep that offered something is never the idle one) and wave 0
+    // of the work-group passes it on with ONE device-scope atomic per sweep -- sixteen members of eight waves each bumping GE
+    // themselves made 1 157 atomics per lattice column on one word, one every 36 ns: the word's atomic unit was what a lone read's
+    // sweep waited for (s_waitcnt vmcnt(0) again before wave 0 may call the work-group idle, so that its bump has landed; it looks
+    // at `pend` once more there, behind the idle words of the other waves).  Wave 0 reads GE in every sweep and turns a change into a bump of the work-group's
     // epoch: every wave then sweeps once more, i.e. reads its exchange cells AFTER that value of GE was
     // seen.  A work-group whose waves are all idle, and whose wave 0 still reads the GE it last imported,
     // writes GE+1 into its idle word; when every member's word says GE+1 and GE is still the same,
@@ -593,8 +597,8 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
         const unsigned e0 = __hip_atomic_load(epochL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (ln == 0) __hip_atomic_store(&idleL[wv], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         int changed = 0, sentX = 0;
-        unsigned geNow = geSeen;
-        if constexpr (G_ > 1) { if (wv == 0) geNow = wLoad(&SY[0]); }
+        unsigned geNow = geSeen, pendSeen = 0;
+        if constexpr (G_ > 1) { if (wv == 0) { geNow = wLoad(&SY[0]); pendSeen = __hip_atomic_load(pendL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } }
         auto loadInbox = [&](auto setc) {
           constexpr int q = setc.value;
           static_for<0, DNAS_GROWS / 2>([&](auto mc) {
@@ -716,10 +720,16 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
           // stragglers, and for this sweep's own offers)
           if (pendingBump) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (ln == 0) __hip_atomic_fetch_add(&SY[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ln == 0) __hip_atomic_fetch_add(pendL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             pendingBump = false;
           }
           if (__any(sentX)) pendingBump = true;   // GE is bumped once these offers have completed: in the next sweep
+          // wave 0 tells the cluster what the work-group's waves have reported (as read at the start of this sweep: the count is
+          // taken off, what came in since stays for the next sweep)
+          if (wv == 0 && pendSeen != 0u && ln == 0) {
+            __hip_atomic_fetch_sub(pendL, pendSeen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&SY[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
           if (wv == 0 && geNow != geSeen) { geSeen = geNow; changed = 1; }   // import: everybody sweeps once more
           // confirmation: nothing moved in this sweep -- then the cells loaded IN this sweep must show nothing new either
           if (!__any(changed)) foldInbox(IntC<0>{});
@@ -750,6 +760,18 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
 #ifdef DNAS_STAMP
             tw0 = __builtin_amdgcn_s_memtime();
 #endif
+            {
+              // every wave of the work-group is idle: what they reported last (before their idle words) goes out first -- GE then
+              // differs from what was imported, and the loop below sends everybody through one more sweep
+              const unsigned pnd = __hip_atomic_load(pendL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              if (pnd != 0u) {
+                if (ln == 0) {
+                  __hip_atomic_fetch_sub(pendL, pnd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                  __hip_atomic_fetch_add(&SY[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              }
+            }
             for (unsigned spin = 0;; ++spin) {
               const unsigned w = ln < 2 + G_ ? wLoad(&SY[ln]) : 0u;
               const unsigned ge = __shfl(w, 0, 64), ab = __shfl(w, 1, 64);
