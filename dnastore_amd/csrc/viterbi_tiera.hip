@@ -597,8 +597,8 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
         const unsigned e0 = __hip_atomic_load(epochL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (ln == 0) __hip_atomic_store(&idleL[wv], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         int changed = 0, sentX = 0;
-        unsigned geNow = geSeen, pendSeen = 0;
-        if constexpr (G_ > 1) { if (wv == 0) { geNow = wLoad(&SY[0]); pendSeen = __hip_atomic_load(pendL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } }
+        unsigned geNow = geSeen;
+        if constexpr (G_ > 1) { if (wv == 0) geNow = wLoad(&SY[0]); }
         auto loadInbox = [&](auto setc) {
           constexpr int q = setc.value;
           static_for<0, DNAS_GROWS / 2>([&](auto mc) {
@@ -714,21 +714,25 @@ viterbi_fill_tiera(TierAArgs a, const unsigned* __restrict__ entTab,   // [G][kE
           rowEval(kc, d, sc);
         });
         ++rounds;
-        if constexpr (G_ > 1 && kSplit) loadInbox(IntC<0>{});
         if constexpr (G_ > 1) {
           // the exchange offers of the sweep before have had a sweep to complete: GE may say so now (the wait is for the
-          // stragglers, and for this sweep's own offers)
+          // stragglers, and for this sweep's own offers -- which is why the inbox loads of this sweep go out BEHIND it: in front
+          // of it the wait was for their round trip as well, in every sweep that followed one with offers)
           if (pendingBump) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (ln == 0) __hip_atomic_fetch_add(pendL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             pendingBump = false;
           }
           if (__any(sentX)) pendingBump = true;   // GE is bumped once these offers have completed: in the next sweep
-          // wave 0 tells the cluster what the work-group's waves have reported (as read at the start of this sweep: the count is
-          // taken off, what came in since stays for the next sweep)
-          if (wv == 0 && pendSeen != 0u && ln == 0) {
-            __hip_atomic_fetch_sub(pendL, pendSeen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(&SY[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if constexpr (kSplit) loadInbox(IntC<0>{});
+          // wave 0 tells the cluster what the work-group's waves have reported (the count it reads is taken off, what comes in
+          // behind it stays for the next sweep)
+          if (wv == 0) {
+            const unsigned pendSeen = __hip_atomic_load(pendL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (pendSeen != 0u && ln == 0) {
+              __hip_atomic_fetch_sub(pendL, pendSeen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              __hip_atomic_fetch_add(&SY[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
           }
           if (wv == 0 && geNow != geSeen) { geSeen = geNow; changed = 1; }   // import: everybody sweeps once more
           // confirmation: nothing moved in this sweep -- then the cells loaded IN this sweep must show nothing new either
