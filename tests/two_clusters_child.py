@@ -36,9 +36,16 @@ def main():
     start_file, calls, options = sys.argv[1], int(sys.argv[2]), sys.argv[3]
     import dnastore_amd as da
     m, params, reads = reads_and_model(da)
-    dec = da.ViterbiDecoder(m, params, options=options)
-    dec.decode(reads)                           # code object loaded, the arena of a full call allocated (hipMalloc of tens of GB
-    #                                             beside another process's can take seconds: tools/alloc_probe.py)
+    # The model and the arena of a full call are made ONE PROCESS AT A TIME: hipMalloc of tens of GB stalls whoever else talks to the
+    # driver -- a kernel of the other process included, for seconds (tools/alloc_probe.py) --, and a cluster launch that is held up
+    # for longer than its watchdog allows gives up with DNAS_E_DEVICE (seen once in the warm-up of a full test run).  The calls that
+    # the test is about, below, run side by side with everything allocated.
+    import fcntl
+    with open(start_file + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        dec = da.ViterbiDecoder(m, params, options=options)
+        dec.decode(reads)                       # code object loaded, the arena of a full call allocated
+        fcntl.flock(lock, fcntl.LOCK_UN)
     open(start_file + ".%d" % os.getpid(), "w").close()
     while not os.path.exists(start_file):        # both processes start their calls together
         time.sleep(0.002)
