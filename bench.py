@@ -340,10 +340,11 @@ def viterbi_line(ctx, config, variant, n_reads, steps, warmup, cpu_seconds, time
             # ---- BASELINE configs[1] names ONE read: its latency
             if config == 1:
                 # the default plan is the throughput one (512-thread work-groups: the machine on 4 CUs per read); one read alone is
-                # decoded soonest on MORE, smaller members -- 16 work-groups of 512 threads, 8 rows per thread (measured, fill of
-                # one ~980-nt read: 43.9 ms; 5 x 1024 threads: 49.0; 8 x 512: 48.4; 16 x 1024: 71; 32 x 1024: 89-94:
-                # profiles/experiments/r4_single_read_latency.txt)
-                dec_lat = da.ViterbiDecoder(machine, params, device=ctx.local_rank, options="threads=512,cluster=16")
+                # decoded soonest on MORE, smaller members -- 14 work-groups of 1024 threads, 4 rows per thread (measured, fill of
+                # one ~980-nt read with the final kernel: 28.5-28.7 ms; 16 x 1024: 29.0-29.6; 16 x 512: 33.9-34.7; 10 x 1024: 32.7-34.4;
+                # 18 ... 32 x 1024: 33-40; profiles/experiments/r4_single_read_latency.txt.  Before the cluster's epoch was bumped once
+                # per work-group instead of once per wave, wide members lost: 16 x 1024 took 71 ms)
+                dec_lat = da.ViterbiDecoder(machine, params, device=ctx.local_rank, options="threads=1024,cluster=14")
                 dec_lat.decode(my_reads[:1])
                 walls, fills, split = [], [], []
                 for _ in range(3):           # median of three (a cluster whose members land on more than one XCD is slower: the census says)

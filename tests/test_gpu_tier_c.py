@@ -49,6 +49,9 @@ def _substitute(rng, dna, rate):
     ("s16h74l4c4.json", "hello.s16h74.del.fa", dict(), 2, 1024),
     ("s16h74l4c4.json", "hello.s16h74.del.fa", dict(global_=True), 4, 512),
     ("s16h74l4c4.json", "hello.s16h74.del.fa", dict(), 3, 512),
+    # the shape of the single-read plan (bench.py: one read alone on 14 work-groups of 1024 threads), on a fixture machine
+    ("s16h74l4c4.json", "hello.s16h74.del.fa", dict(global_=True), 14, 1024),
+    ("s16h74l4c4.json", "hello.s16h74.fa", dict(), 16, 1024),
 ])
 def test_tier_c_full_lattice_bit_exact(da, oracle_mod, ref_data, mach, fa, flags, members, threads):
     """Both work-group shapes: 512 threads (8 waves, 256 registers each, the tier-C default) and 1024 (tier A's)."""
